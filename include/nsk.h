@@ -1,0 +1,183 @@
+/*
+ * libnsk -- C ABI of the MI355X (gfx950) kernels for the NavierStokes.jl
+ * projection-method time step.
+ *
+ * The reference has no FFI: its boundary is the ParallelStencil call syntax
+ * `@parallel f!(args...)` (scripts/NavierStokes.jl:79-100) on device-resident,
+ * column-major Float64 arrays.  Every entry point below replaces exactly one of
+ * those call sites (cited per function) and keeps the Julia argument order; the
+ * array extents, which Julia carries inside the array objects, follow as
+ * trailing integers.
+ *
+ * Conventions
+ *   - All array arguments are DEVICE pointers to dense column-major Float64
+ *     data, A[ix,iy] at a[(iy-1)*size(A,1) + (ix-1)]  (ix contiguous).
+ *   - nx, ny are the cell counts of the pressure grid of the array window the
+ *     call works on:  Pr, C, divV, txx, tyy are (nx,ny); Vx (nx+1,ny);
+ *     Vy (nx,ny+1); txy (nx-1,ny-1); dPrdtau, Rp (nx-2,ny-2); Vprof (nx).
+ *   - Slab windows: a process that holds rows iy0+1 .. iy0+ny of a global grid
+ *     of nyg rows passes (iy0, nyg); a whole domain passes iy0=0, nyg=ny.
+ *     Interior/boundary guards are evaluated on the global row index, so the
+ *     same kernels serve the single-GPU and the slab-decomposed run.
+ *   - Every function returns 0 on success, nonzero on error; the message is
+ *     available from nsk_last_error() on the calling thread.  No exceptions
+ *     cross the boundary.
+ *   - Calls are asynchronous on the context's HIP stream unless stated
+ *     otherwise.  A context belongs to one host thread.
+ */
+#ifndef NSK_H
+#define NSK_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nsk_ctx nsk_ctx;
+
+/* ---- lifetime / error / stream ------------------------------------------ */
+
+/* Replaces `@init_parallel_stencil(CUDA, Float64, 2)` (NavierStokes.jl:4-8):
+ * binds a context to HIP device `device` and creates its stream and scratch. */
+int nsk_create(int device, nsk_ctx **out);
+int nsk_destroy(nsk_ctx *ctx);
+const char *nsk_last_error(void);
+const char *nsk_version(void);
+/* Use an existing hipStream_t (e.g. the host framework's) instead of the
+ * context's own; pass NULL to return to the context's own stream. */
+int nsk_set_stream(nsk_ctx *ctx, void *hip_stream);
+/* Blocks until all work queued on the context's stream is done. */
+int nsk_sync(nsk_ctx *ctx);
+
+/* ---- memory (mirrors @zeros / Array(A) / A .= B) ------------------------- */
+
+/* `@zeros(n1,n2)` (NavierStokes.jl:58-70). */
+int nsk_zeros(nsk_ctx *ctx, int n1, int n2, double **out);
+int nsk_free(nsk_ctx *ctx, double *dev);
+/* `Data.Array(host)` (NavierStokes.jl:72); synchronous. */
+int nsk_upload(nsk_ctx *ctx, double *dev, const double *host, size_t count);
+/* `Array(A)` (NavierStokes.jl:75,109); synchronous. */
+int nsk_download(nsk_ctx *ctx, double *host, const double *dev, size_t count);
+/* `A_o .= A` (NavierStokes.jl:99). */
+int nsk_copy(nsk_ctx *ctx, double *dst, const double *src, size_t count);
+
+/* ---- kernel-granular entry points, 1:1 with the @parallel call sites ----- */
+
+/* update_τ!   NavierStokes.jl:116-121, call site :79 */
+int nsk_update_tau(nsk_ctx *ctx, double *txx, double *tyy, double *txy,
+                   const double *Vx, const double *Vy, double mu, double dx,
+                   double dy, int nx, int ny);
+/* predict_V!  NavierStokes.jl:123-127, call site :80 */
+int nsk_predict_V(nsk_ctx *ctx, double *Vx, double *Vy, const double *txx,
+                  const double *tyy, const double *txy, double rho, double g,
+                  double dt, double dx, double dy, int nx, int ny);
+/* set_sphere! NavierStokes.jl:225-250, call sites :81,:97 */
+int nsk_set_sphere(nsk_ctx *ctx, double *C, double *Vx, double *Vy, double a2,
+                   double b2, double ox, double oy, double sinb, double cosb,
+                   double lx, double ly, double dx, double dy, int nx, int ny,
+                   int iy0);
+/* update_∇V!  NavierStokes.jl:129-132, call site :82 */
+int nsk_update_divV(nsk_ctx *ctx, double *divV, const double *Vx,
+                    const double *Vy, double dx, double dy, int nx, int ny);
+/* update_dPrdτ! NavierStokes.jl:134-137, call site :85 */
+int nsk_update_dPrdtau(nsk_ctx *ctx, const double *Pr, double *dPrdtau,
+                       const double *divV, double rho, double dt, double dtau,
+                       double damp, double dx, double dy, int nx, int ny);
+/* update_Pr!  NavierStokes.jl:139-142, call site :86 */
+int nsk_update_Pr(nsk_ctx *ctx, double *Pr, const double *dPrdtau, double dtau,
+                  int nx, int ny);
+/* set_bc_Pr!  NavierStokes.jl:186-190 (bc_x! :155-159 then bc_yval! :173-177),
+ * call site :87.  full_rows=0 reproduces the reference's launch range of
+ * bc_x!, which covers only rows iy <= size(A,1); full_rows=1 covers all rows. */
+int nsk_set_bc_Pr(nsk_ctx *ctx, double *Pr, double val, int nx, int ny,
+                  int full_rows, int iy0, int nyg);
+/* compute_res! NavierStokes.jl:144-147, call site :89 */
+int nsk_compute_res(nsk_ctx *ctx, double *Rp, const double *Pr,
+                    const double *divV, double rho, double dt, double dx,
+                    double dy, int nx, int ny);
+/* maximum(abs.(A)) NavierStokes.jl:90; NaN-propagating; synchronous. */
+int nsk_maxabs(nsk_ctx *ctx, const double *A, size_t count, double *out);
+/* correct_V!  NavierStokes.jl:149-153, call site :96 */
+int nsk_correct_V(nsk_ctx *ctx, double *Vx, double *Vy, const double *Pr,
+                  double dt, double rho, double dx, double dy, int nx, int ny);
+/* set_bc_Vel! NavierStokes.jl:179-184 (bc_y!(Vx), bc_x!(Vy), bc_yV!(Vy,Vprof)),
+ * call site :98 */
+int nsk_set_bc_Vel(nsk_ctx *ctx, double *Vx, double *Vy, const double *Vprof,
+                   int nx, int ny, int full_rows, int iy0, int nyg);
+/* advect! (+ backtrack!, lerp) NavierStokes.jl:192-223, call site :100 */
+int nsk_advect(nsk_ctx *ctx, double *Vx, const double *Vx_o, double *Vy,
+               const double *Vy_o, double *C, const double *C_o, double dt,
+               double dx, double dy, int nx, int ny, int iy0, int nyg);
+
+/* ---- fused entry points --------------------------------------------------- */
+
+/* Scalars of runme(), NavierStokes.jl:14-56, plus the slab window and the
+ * storage of the three Poisson fields.
+ *
+ * Storage: the fused entry points accept pitched fields.  Pr and divV share
+ * the leading dimension ld_pr (0 = dense, nx).  dPrdtau either is the
+ * reference's (nx-2, ny-2) array with leading dimension ld_dp (0 = dense,
+ * nx-2; pointer at its element [1,1]), or -- dp_embedded = 1 -- an array laid
+ * out exactly like Pr (same extents and ld_pr; pointer at its first element)
+ * whose element for pressure cell (ix,iy) sits at the same offset as
+ * Pr[ix,iy]; its rows 1, ny and columns 1, nx are unused.  The vectorised
+ * kernels run when dp_embedded = 1, ld_pr is even and the three pointers are
+ * 16-byte aligned; any other storage runs the same arithmetic with 8-byte
+ * accesses. */
+typedef struct nsk_ns_params {
+  int nx, ny;        /* window extents (ny = rows held by this process) */
+  int iy0, nyg;      /* global row offset and global row count          */
+  int niter, nchk;   /* NavierStokes.jl:42-43                            */
+  int full_rows;     /* 0 = reference launch range of bc_x!              */
+  int ld_pr;         /* leading dimension of Pr and divV, 0 = nx         */
+  int ld_dp;         /* leading dimension of dPrdtau, 0 = nx-2           */
+  int dp_embedded;   /* 1 = dPrdtau stored on the Pr layout (see above)  */
+  double lx, ly, rho, vin, psc, mu, g, a2, b2, ox, oy, sinb, cosb;
+  double eps_it, dx, dy, dt, damp, dtau;
+} nsk_ns_params;
+
+/* `count` consecutive passes of NavierStokes.jl:85-87
+ * (update_dPrdτ!, update_Pr!, set_bc_Pr!(Pr,0.0)) with no residual check.
+ * Asynchronous.  Rows 1 and ny of the window are physical boundaries only
+ * when they are rows 1 / nyg of the global grid; otherwise they are halo rows
+ * and are left untouched (after `count` passes the outermost `count` halo
+ * rows of Pr and dPrdtau are stale and must be exchanged by the caller). */
+int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau,
+                         const double *divV, const nsk_ns_params *p, int count);
+
+/* Residual of NavierStokes.jl:89-90 on the window: writes Rp (may be NULL)
+ * and returns max|Rp| over the rows this window owns (rows own_lo..own_hi,
+ * 1-based window rows of Pr; pass 2 and ny-1 for a whole domain).
+ * Synchronous. */
+int nsk_ns_residual(nsk_ctx *ctx, double *Rp, const double *Pr,
+                    const double *divV, const nsk_ns_params *p, int own_lo,
+                    int own_hi, double *maxabs_out);
+
+/* The whole Poisson loop NavierStokes.jl:84-95 on a single domain: iterates in
+ * chunks of nchk, evaluates err = max|Rp|*ly^2/psc after each chunk and stops
+ * when err < eps_it or err is not finite.  err_hist/iter_hist (host, capacity
+ * hist_cap, may be NULL) receive the (iter, err) pairs the reference prints at
+ * :92.  Synchronous. */
+int nsk_ns_poisson(nsk_ctx *ctx, double *Pr, double *dPrdtau, double *Rp,
+                   const double *divV, const nsk_ns_params *p, int *iters_out,
+                   double *err_hist, int *iter_hist, int hist_cap,
+                   int *nhist_out);
+
+/* Device arrays of runme(), NavierStokes.jl:58-72.  Pr, dPrdtau and divV are
+ * stored as the parameter block says; all other arrays are dense. */
+typedef struct nsk_ns_state {
+  double *Pr, *dPrdtau, *C, *C_o, *txx, *tyy, *txy, *Vx, *Vy, *Vx_o, *Vy_o,
+      *divV, *Rp, *Vprof;
+} nsk_ns_state;
+
+/* One pass of the time-loop body NavierStokes.jl:79-100 on a single domain.
+ * Synchronous (the Poisson loop reads the residual back). */
+int nsk_ns_step(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_params *p,
+                int *iters_out, double *err_hist, int *iter_hist, int hist_cap,
+                int *nhist_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSK_H */

@@ -1,0 +1,136 @@
+"""ctypes binding of libnsk.so (the C ABI declared in include/nsk.h).
+
+There is no CPU fallback: importing this module without the built library, or
+calling into it without a GPU, raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnsk.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+
+class NskError(RuntimeError):
+    pass
+
+
+class CNSParams(C.Structure):
+    """struct nsk_ns_params (include/nsk.h)."""
+    _fields_ = [
+        ("nx", C.c_int), ("ny", C.c_int), ("iy0", C.c_int), ("nyg", C.c_int),
+        ("niter", C.c_int), ("nchk", C.c_int), ("full_rows", C.c_int),
+        ("ld_pr", C.c_int), ("ld_dp", C.c_int), ("dp_embedded", C.c_int),
+        ("lx", C.c_double), ("ly", C.c_double), ("rho", C.c_double), ("vin", C.c_double),
+        ("psc", C.c_double), ("mu", C.c_double), ("g", C.c_double), ("a2", C.c_double),
+        ("b2", C.c_double), ("ox", C.c_double), ("oy", C.c_double), ("sinb", C.c_double),
+        ("cosb", C.c_double), ("eps_it", C.c_double), ("dx", C.c_double), ("dy", C.c_double),
+        ("dt", C.c_double), ("damp", C.c_double), ("dtau", C.c_double),
+    ]
+
+
+class CNSState(C.Structure):
+    """struct nsk_ns_state (include/nsk.h)."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "Pr", "dPrdtau", "C", "C_o", "txx", "tyy", "txy", "Vx", "Vy", "Vx_o", "Vy_o",
+        "divV", "Rp", "Vprof")]
+
+
+_D, _I, _P, _S = C.c_double, C.c_int, C.c_void_p, C.c_size_t
+
+# name -> argtypes (after the leading context pointer); all return int
+_SIGS = {
+    "nsk_update_tau": [_P, _P, _P, _P, _P, _D, _D, _D, _I, _I],
+    "nsk_predict_V": [_P, _P, _P, _P, _P, _D, _D, _D, _D, _D, _I, _I],
+    "nsk_set_sphere": [_P, _P, _P] + [_D] * 10 + [_I, _I, _I],
+    "nsk_update_divV": [_P, _P, _P, _D, _D, _I, _I],
+    "nsk_update_dPrdtau": [_P, _P, _P, _D, _D, _D, _D, _D, _D, _I, _I],
+    "nsk_update_Pr": [_P, _P, _D, _I, _I],
+    "nsk_set_bc_Pr": [_P, _D, _I, _I, _I, _I, _I],
+    "nsk_compute_res": [_P, _P, _P, _D, _D, _D, _D, _I, _I],
+    "nsk_maxabs": [_P, _S, c_double_p],
+    "nsk_correct_V": [_P, _P, _P, _D, _D, _D, _D, _I, _I],
+    "nsk_set_bc_Vel": [_P, _P, _P, _I, _I, _I, _I, _I],
+    "nsk_advect": [_P, _P, _P, _P, _P, _P, _D, _D, _D, _I, _I, _I, _I],
+    "nsk_copy": [_P, _P, _S],
+    "nsk_upload": [_P, _P, _S],
+    "nsk_download": [_P, _P, _S],
+    "nsk_free": [_P],
+    "nsk_zeros": [_I, _I, C.POINTER(_P)],
+    "nsk_set_stream": [_P],
+    "nsk_sync": [],
+    "nsk_ns_poisson_iters": [_P, _P, _P, C.POINTER(CNSParams), _I],
+    "nsk_ns_residual": [_P, _P, _P, C.POINTER(CNSParams), _I, _I, c_double_p],
+    "nsk_ns_poisson": [_P, _P, _P, _P, C.POINTER(CNSParams), c_int_p, c_double_p, c_int_p, _I, c_int_p],
+    "nsk_ns_step": [C.POINTER(CNSState), C.POINTER(CNSParams), c_int_p, c_double_p, c_int_p, _I, c_int_p],
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libnsk.so; raises NskError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NskError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C navierstokes_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.nsk_last_error.restype = C.c_char_p
+    lib.nsk_version.restype = C.c_char_p
+    lib.nsk_create.argtypes = [_I, C.POINTER(_P)]
+    lib.nsk_create.restype = _I
+    lib.nsk_destroy.argtypes = [_P]
+    lib.nsk_destroy.restype = _I
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [_P] + args
+        fn.restype = _I
+    _lib = lib
+    return lib
+
+
+def exported_names() -> list[str]:
+    return ["nsk_create", "nsk_destroy", "nsk_last_error", "nsk_version"] + list(_SIGS)
+
+
+class Context:
+    """One nsk_ctx bound to a HIP device; methods are the C entry points without the nsk_ prefix."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load()
+        h = _P()
+        rc = self.lib.nsk_create(int(device), C.byref(h))
+        if rc != 0:
+            raise NskError(self.lib.nsk_last_error().decode())
+        self.handle = h
+        if stream is not None:
+            self.call("nsk_set_stream", _P(stream))
+
+    def call(self, name: str, *args) -> None:
+        rc = getattr(self.lib, name)(self.handle, *args)
+        if rc != 0:
+            raise NskError(f"{name}: {self.lib.nsk_last_error().decode()}")
+
+    def __getattr__(self, name):
+        if name.startswith("_") or ("nsk_" + name) not in _SIGS:
+            raise AttributeError(name)
+        full = "nsk_" + name
+        return lambda *a: self.call(full, *a)
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.nsk_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

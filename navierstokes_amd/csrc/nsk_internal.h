@@ -1,0 +1,55 @@
+// Internal declarations shared by the libnsk translation units (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/nsk.h"
+
+struct nsk_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;  // stream in use (own_stream or the caller's)
+  // Reduction slot for max|.| (bit pattern of a non-negative double) and its
+  // pinned host mirror.
+  unsigned long long *red_dev = nullptr;
+  unsigned long long *red_host = nullptr;
+  // Ping-pong partners of Pr / dPrdtau for the multi-iteration Poisson kernel,
+  // (re)allocated on demand by the fused entry points.
+  double *pp_pr = nullptr, *pp_dp = nullptr;
+  size_t pp_elems = 0;
+  int poisson_k = 0;  // 0 = library default; set by NSK_POISSON_K / nsk_set_option
+};
+
+void nsk_set_error(const char *fmt, ...);
+
+#define NSK_HIP(call)                                                          \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      nsk_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
+                    __FILE__, __LINE__);                                       \
+      return 1;                                                                \
+    }                                                                          \
+  } while (0)
+
+#define NSK_REQUIRE(cond, ...)                                                 \
+  do {                                                                         \
+    if (!(cond)) {                                                             \
+      nsk_set_error(__VA_ARGS__);                                              \
+      return 2;                                                                \
+    }                                                                          \
+  } while (0)
+
+#define NSK_CTX(ctx)                                                           \
+  NSK_REQUIRE((ctx) != nullptr, "null context");                               \
+  NSK_HIP(hipSetDevice((ctx)->device))
+
+#define NSK_LAUNCH_CHECK() NSK_HIP(hipGetLastError())
+
+// Column-major element: A[ix,iy], 1-based like the reference's kernels.
+#define A2(a, ld, ix, iy) (a)[(size_t)((iy)-1) * (size_t)(ld) + (size_t)((ix)-1)]
+
+static inline unsigned nsk_cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }

@@ -1,0 +1,123 @@
+"""The hot path: K passes of update_dPrdτ! + update_Pr! + set_bc_Pr! per launch
+(scripts/NavierStokes.jl:85-87) against the oracle's pass-by-pass loop, bit for bit, for every
+pass count per launch, both storage forms, whole domains and slab windows."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from navierstokes_amd import ns_params
+from navierstokes_amd.ns import c_params, _pitch
+from util import Dev, rng_field, same_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_iters(oracle, p, Pr, dP, divV, count, full):
+    for _ in range(count):
+        oracle.update_dPrdtau(Pr, dP, divV, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy)
+        oracle.update_Pr(Pr, dP, p.dtau)
+        oracle.set_bc_Pr(Pr, 0.0, bool(full))
+
+
+def run_gpu(gpu, p, Pr, dP, divV, count, full, pitched, kmax=None, iy0=0, nyg=None):
+    nx, ny = Pr.shape
+    if pitched:
+        ld = _pitch(nx)
+        dPr, dDv = Dev(Pr, ld, pad_value=np.nan), Dev(divV, ld, pad_value=np.nan)
+        emb = np.full((nx, ny), np.nan, order="F")
+        emb[1:-1, 1:-1] = dP
+        dDp = Dev(emb, ld, pad_value=np.nan)
+        cp = c_params(p.with_(full_rows=bool(full)), ld_pr=ld, dp_embedded=1, iy0=iy0, nyg=nyg, ny=ny)
+    else:
+        dPr, dDv, dDp = Dev(Pr), Dev(divV), Dev(dP)
+        cp = c_params(p.with_(full_rows=bool(full)), iy0=iy0, nyg=nyg, ny=ny)
+    gpu.ns_poisson_iters(dPr.ptr, dDp.ptr, dDv.ptr, C.byref(cp), count)
+    out_dp = dDp.get()
+    return dPr.get(), (np.asfortranarray(out_dp[1:-1, 1:-1]) if pitched else out_dp)
+
+
+@pytest.mark.parametrize("pitched", [False, True])
+@pytest.mark.parametrize("nx,ny", [(3, 3), (4, 7), (5, 4), (9, 33), (121, 40), (130, 67), (153, 255), (255, 153), (300, 97)])
+def test_poisson_iters_whole_domain(gpu, oracle, nx, ny, pitched, monkeypatch):
+    rng = np.random.default_rng(nx * 7919 + ny)
+    p = ns_params("NavierStokes", nx=nx, ny=ny)
+    Pr0, dP0, dv = rng_field(rng, nx, ny), rng_field(rng, nx - 2, ny - 2), rng_field(rng, nx, ny, 10.0)
+    for full in (0, 1):
+        if full == 0 and nx > ny:
+            continue
+        for count in (1, 2, 3, 4, 5, 8, 11):
+            Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
+            oracle_iters(oracle, p, Pr, dP, dv, count, full)
+            gPr, gdP = run_gpu(gpu, p, Pr0, dP0, dv, count, full, pitched)
+            assert same_bits(gPr, Pr), (count, full, np.argwhere(gPr != Pr)[:5])
+            assert same_bits(gdP, dP), (count, full, np.argwhere(gdP != dP)[:5])
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_poisson_every_pass_count(oracle, k, monkeypatch):
+    """Each templated pass count per launch (library option NSK_POISSON_K) on the default grid."""
+    import torch
+    from navierstokes_amd import _lib
+    monkeypatch.setenv("NSK_POISSON_K", str(k))
+    ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        nx, ny = 153, 255
+        rng = np.random.default_rng(k)
+        p = ns_params("NavierStokes")
+        Pr0, dP0, dv = rng_field(rng, nx, ny), rng_field(rng, nx - 2, ny - 2), rng_field(rng, nx, ny, 10.0)
+        for pitched in (False, True):
+            for count in (k, 2 * k, 2 * k + 1):
+                Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
+                oracle_iters(oracle, p, Pr, dP, dv, count, 0)
+                gPr, gdP = run_gpu(ctx, p, Pr0, dP0, dv, count, 0, pitched)
+                assert same_bits(gPr, Pr) and same_bits(gdP, dP), (pitched, count)
+    finally:
+        ctx.close()
+
+
+def test_poisson_loop_with_checks(gpu, oracle):
+    """nsk_ns_poisson = NavierStokes.jl:84-95 incl. the residual checks and the early exit."""
+    p = ns_params("NavierStokes", nx=63, ny=105)
+    nx, ny = p.nx, p.ny
+    rng = np.random.default_rng(5)
+    Pr0, dP0 = np.zeros((nx, ny), order="F"), np.zeros((nx - 2, ny - 2), order="F")
+    dv = rng_field(rng, nx, ny, 0.05)
+    Pr, dP, Rp = Pr0.copy(order="F"), dP0.copy(order="F"), np.zeros((nx - 2, ny - 2), order="F")
+    it, ih, eh = oracle.poisson(Pr, dP, Rp, dv, p)
+    assert 0 < it < p.niter, "test wants an early exit"
+    dPr, dDp, dDv, dRp = Dev(Pr0), Dev(dP0), Dev(dv), Dev(Rp * 0)
+    cp = c_params(p)
+    iters, nh = C.c_int(0), C.c_int(0)
+    he, hi = (C.c_double * 256)(), (C.c_int * 256)()
+    gpu.ns_poisson(dPr.ptr, dDp.ptr, dRp.ptr, dDv.ptr, C.byref(cp), C.byref(iters), he, hi, 256, C.byref(nh))
+    assert iters.value == it and nh.value == len(ih)
+    assert list(hi[: nh.value]) == ih and list(he[: nh.value]) == eh
+    assert same_bits(dPr.get(), Pr) and same_bits(dDp.get(), dP) and same_bits(dRp.get(), Rp)
+
+
+def test_poisson_slab_windows(gpu, oracle):
+    """A window of a taller global grid: its first/last rows are halo rows that must stay untouched,
+    and after `count` passes all rows further than `count` from a halo edge equal the global result."""
+    nx, nyg, count = 70, 96, 4
+    p = ns_params("NavierStokes", nx=nx, ny=nyg)
+    rng = np.random.default_rng(11)
+    Pr0, dP0, dv = rng_field(rng, nx, nyg), rng_field(rng, nx - 2, nyg - 2), rng_field(rng, nx, nyg, 10.0)
+    Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
+    oracle_iters(oracle, p, Pr, dP, dv, count, 0)
+    for lo, hi in [(0, 40), (30, 75), (60, 96)]:   # global 0-based row ranges [lo, hi)
+        wPr = np.asfortranarray(Pr0[:, lo:hi])
+        wdv = np.asfortranarray(dv[:, lo:hi])
+        wdP = np.asfortranarray(dP0[:, lo:hi - 2])     # dP row j <-> Pr row j+1
+        for pitched in (False, True):
+            gPr, gdP = run_gpu(gpu, p, wPr, wdP, wdv, count, 0, pitched, iy0=lo, nyg=nyg)
+            a = 0 if lo == 0 else count
+            b = (hi - lo) if hi == nyg else (hi - lo) - count
+            assert same_bits(gPr[:, a:b], Pr[:, lo + a:lo + b]), (lo, hi, pitched)
+            nyw = hi - lo
+            pa, pb = max(a, 1), min(b, nyw - 1)            # window Pr rows whose dPrdτ is valid
+            assert same_bits(gdP[:, pa - 1:pb - 1], dP[:, lo + pa - 1:lo + pb - 1]), (lo, hi, pitched)
+            if lo > 0:
+                assert same_bits(gPr[:, 0], wPr[:, 0])
+            if hi < nyg:
+                assert same_bits(gPr[:, -1], wPr[:, -1])
