@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: the pseudo-transient pressure-Poisson loop of
+scripts/NavierStokes_Re6.jl (2559 x 4095, Float64) on N MI355X.
+
+One bench "step" = one residual-check interval of the reference's Poisson loop
+(NavierStokes_Re6.jl:84-95): nchk = 4*(nx-1) = 10232 passes of update_dPrdτ! + update_Pr! +
+set_bc_Pr! followed by compute_res! + max|Rp| -- the smallest unit of Poisson work a time step
+performs (a time step runs 1..12 of them).  T_eff follows the ParallelStencil convention:
+algorithmic bytes = (2 + 2 + 1) fields x 8 B = 40 B per cell and pass.
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1 is weak scaling: every rank owns a 2559 x 4095 slab of a 2559 x (4095 N) grid; halos
+travel over RCCL (navierstokes_amd/dist.py).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
+
+
+def cpu_baseline(p, seconds_target=15.0):
+    """The oracle's OpenMP build (same loops, outer index threaded like ParallelStencil's Threads
+    backend) timed on this host: a bounded number of Poisson passes on the same 2559 x 4095 fields."""
+    from oracle.ns_oracle import Oracle, farray
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    o = Oracle(omp=True)
+    nx, ny = p.nx, p.ny
+    rng = np.random.default_rng(1234)
+    Pr = np.asfortranarray(rng.standard_normal((nx, ny)) * 1e-2)
+    dv = np.asfortranarray(rng.standard_normal((nx, ny)) * 1e-2)
+    dP = farray(nx - 2, ny - 2)
+
+    def passes(n):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            o.update_dPrdtau(Pr, dP, dv, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy)
+            o.update_Pr(Pr, dP, p.dtau)
+            o.set_bc_Pr(Pr, 0.0, p.full_rows)
+        return time.perf_counter() - t0
+
+    t1 = passes(2)                                   # warm-up + calibration
+    n = max(4, min(400, int(seconds_target / max(t1 / 2, 1e-4))))
+    t = passes(n)
+    t_iter = t / n
+    return {"value": 40.0 * nx * ny / t_iter / 1e9, "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": f"{n} Poisson passes at {nx}x{ny} (oracle, OpenMP over iy), {t_iter*1e3:.2f} ms/pass",
+            "steps_per_s_at_nchk": 1.0 / (t_iter * p.nchk)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=16, help="runme(n=...): nx=160n-1, ny=256n-1 per GPU")
+    ap.add_argument("--halo", type=int, default=32, help="halo rows = passes between exchanges (N>1)")
+    ap.add_argument("--passes", type=int, default=0, help="passes per step (default nchk)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--time-steps", type=int, default=0,
+                    help="additionally run this many whole reference time steps from the IC (N=1)")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from navierstokes_amd import _lib, ns_params
+    from navierstokes_amd.dist import HipBackend, SlabPoisson, exchange_rows, make_slab
+    from navierstokes_amd.ns import _pitch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    p1 = ns_params("NavierStokes_Re6", n=a.n)                   # one GPU's slab
+    nx, ny_loc = p1.nx, p1.ny
+    slab = make_slab(rank, world, ny_loc, a.halo)
+    # global problem: same scalars, ly grows with the number of slabs (dy, dt, dτ unchanged)
+    p = p1.with_(ny=ny_loc * world, ly=p1.ly * world) if world > 1 else p1
+    passes = a.passes or p1.nchk
+    ld = _pitch(nx)
+    ctx = _lib.Context(local, torch.cuda.current_stream().cuda_stream)
+
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    def rnd():
+        t = torch.zeros((slab.ny_win, ld), dtype=torch.float64)
+        t[:, :nx] = torch.randn((slab.ny_win, nx), generator=g, dtype=torch.float64) * 1e-2
+        return t.to(dev)
+    Pr, divV = rnd(), rnd()
+    dP = torch.zeros((slab.ny_win, ld), dtype=torch.float64, device=dev)
+    exchange_rows((Pr, divV), slab)
+    be = HipBackend(ctx, p, ld)
+    sp = SlabPoisson(p, slab, be, Pr, dP, divV)
+
+    def step():
+        sp.iterate(passes)
+        return sp.residual()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        err = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # dominant kernel, timed on the stream it runs on: launches of K passes back to back
+    kpl = ctx.get_option("poisson_k")
+    nl = 64
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    be.poisson_iters(Pr, dP, divV, slab, kpl * 2)
+    torch.cuda.synchronize()
+    e0.record()
+    be.poisson_iters(Pr, dP, divV, slab, kpl * nl)
+    e1.record()
+    torch.cuda.synchronize()
+    t_launch = e0.elapsed_time(e1) * 1e-3 / nl
+    alg_bytes = 40.0 * nx * slab.ny_win * kpl
+    achieved = alg_bytes / t_launch / 1e9
+
+    traffic = None
+    try:   # HBM bytes per launch measured with rocprofv3 PMC passes for this kernel and grid
+        with open(os.path.join(ROOT, "profiles", "poisson_traffic.json")) as f:
+            t = json.load(f).get(f"k_poisson<{kpl}>")
+        if t and a.n == 16 and world == 1:
+            traffic = t["read_bytes"] + t["write_bytes"]
+    except OSError:
+        pass
+
+    cells = nx * ny_loc * world
+    t_iter = dt / (a.steps * passes)
+    teff = 40.0 * cells / t_iter / 1e9
+    out = {
+        "metric": "T_eff", "value": teff, "unit": "GB/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"NavierStokes_Re6.jl Poisson loop, {nx}x{ny_loc} cells per GPU, "
+                               f"{passes} passes + 1 residual check per step",
+                   "grid_per_gpu": [nx, ny_loc], "passes_per_step": passes,
+                   "parallelism": f"slab{world}" if world > 1 else "single",
+                   "halo_rows": slab.halo, "passes_per_launch": kpl},
+        "t_iter_us": t_iter * 1e6,
+        "pct_of_hbm_peak": teff / (HBM_PEAK_GBS * world) * 100.0,
+        "time_steps_per_s_at_min_iters": 1.0 / (t_iter * p1.nchk),
+        "last_err": err,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": f"k_poisson<{kpl}>", "launch_us": t_launch * 1e6,
+                     "algorithmic_bytes_per_launch": alg_bytes},
+    }
+    if rank == 0 and world == 1 and a.time_steps > 0:
+        from navierstokes_amd.ns import NavierStokes
+        sim = NavierStokes(p1, device=f"cuda:{local}")
+        its = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.time_steps):
+            its.append(sim.step())
+        torch.cuda.synchronize()
+        tts = time.perf_counter() - t0
+        out["time_steps"] = {"steps": a.time_steps, "steps_per_s": a.time_steps / tts,
+                             "poisson_iters": its, "from": "reference initial condition"}
+    if rank == 0 and world == 1 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(p1)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,9 +44,17 @@ int nsk_create(int device, nsk_ctx **out);
 int nsk_destroy(nsk_ctx *ctx);
 const char *nsk_last_error(void);
 const char *nsk_version(void);
-/* Use an existing hipStream_t (e.g. the host framework's) instead of the
- * context's own; pass NULL to return to the context's own stream. */
+/* Use an existing hipStream_t (e.g. the host framework's current stream)
+ * instead of the context's own; NULL is HIP's default stream. */
 int nsk_set_stream(nsk_ctx *ctx, void *hip_stream);
+/* Return to the stream the context created for itself. */
+int nsk_use_own_stream(nsk_ctx *ctx);
+/* Tuning knobs with no counterpart in the reference:
+ *   "poisson_k"    passes of the Poisson iteration evaluated per kernel launch
+ *                  (1..8, 0 = default); results are bit-identical for every value
+ *   "poisson_rows" rows per wavefront task of that kernel (0 = automatic)      */
+int nsk_set_option(nsk_ctx *ctx, const char *name, int value);
+int nsk_get_option(nsk_ctx *ctx, const char *name, int *value);
 /* Blocks until all work queued on the context's stream is done. */
 int nsk_sync(nsk_ctx *ctx);
 

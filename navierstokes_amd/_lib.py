@@ -62,6 +62,9 @@ _SIGS = {
     "nsk_free": [_P],
     "nsk_zeros": [_I, _I, C.POINTER(_P)],
     "nsk_set_stream": [_P],
+    "nsk_use_own_stream": [],
+    "nsk_set_option": [C.c_char_p, _I],
+    "nsk_get_option": [C.c_char_p, c_int_p],
     "nsk_sync": [],
     "nsk_ns_poisson_iters": [_P, _P, _P, C.POINTER(CNSParams), _I],
     "nsk_ns_residual": [_P, _P, _P, C.POINTER(CNSParams), _I, _I, c_double_p],
@@ -81,6 +84,9 @@ def load() -> C.CDLL:
         raise NskError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C navierstokes_amd/csrc` (there is no CPU fallback)")
+    # PyTorch ships its own HIP runtime; libnsk must bind to that same instance (streams and
+    # device pointers are shared with torch), so torch has to be loaded before the library.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.nsk_last_error.restype = C.c_char_p
     lib.nsk_version.restype = C.c_char_p
@@ -119,10 +125,18 @@ class Context:
             raise NskError(f"{name}: {self.lib.nsk_last_error().decode()}")
 
     def __getattr__(self, name):
-        if name.startswith("_") or ("nsk_" + name) not in _SIGS:
+        if name.startswith("_") or name in ("set_option", "get_option") or ("nsk_" + name) not in _SIGS:
             raise AttributeError(name)
         full = "nsk_" + name
         return lambda *a: self.call(full, *a)
+
+    def set_option(self, name: str, value: int) -> None:
+        self.call("nsk_set_option", name.encode(), int(value))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        self.call("nsk_get_option", name.encode(), C.byref(v))
+        return v.value
 
     def close(self) -> None:
         if getattr(self, "handle", None):

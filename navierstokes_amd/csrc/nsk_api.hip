@@ -38,31 +38,77 @@ extern "C" int nsk_create(int device, nsk_ctx **out) {
     nsk_destroy(c);
     return 1;
   }
-  const char *k = getenv("NSK_POISSON_K");
-  if (k) c->poisson_k = atoi(k);
+  if (const char *k = getenv("NSK_POISSON_K")) c->poisson_k = atoi(k);
+  if (const char *r = getenv("NSK_POISSON_ROWS")) c->poisson_rows = atoi(r);
   *out = c;
   return 0;
 }
 
 extern "C" int nsk_destroy(nsk_ctx *c) {
   if (!c) return 0;
-  hipSetDevice(c->device);
+  (void)hipSetDevice(c->device);
   if (c->own_stream) {
-    hipStreamSynchronize(c->own_stream);
-    hipStreamDestroy(c->own_stream);
+    (void)hipStreamSynchronize(c->own_stream);
+    (void)hipStreamDestroy(c->own_stream);
   }
-  if (c->red_dev) hipFree(c->red_dev);
-  if (c->red_host) hipHostFree(c->red_host);
-  if (c->pp_pr) hipFree(c->pp_pr);
-  if (c->pp_dp) hipFree(c->pp_dp);
+  if (c->red_dev) (void)hipFree(c->red_dev);
+  if (c->red_host) (void)hipHostFree(c->red_host);
+  if (c->pp_pr) (void)hipFree(c->pp_pr);
+  if (c->pp_dp) (void)hipFree(c->pp_dp);
   delete c;
   return 0;
 }
 
 extern "C" int nsk_set_stream(nsk_ctx *ctx, void *hip_stream) {
   NSK_REQUIRE(ctx != nullptr, "null context");
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  ctx->stream = (hipStream_t)hip_stream;  // NULL is HIP's default stream
   return 0;
+}
+
+extern "C" int nsk_use_own_stream(nsk_ctx *ctx) {
+  NSK_REQUIRE(ctx != nullptr, "null context");
+  ctx->stream = ctx->own_stream;
+  return 0;
+}
+
+extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
+  NSK_REQUIRE(ctx != nullptr && name != nullptr, "nsk_set_option: null argument");
+  if (!strcmp(name, "poisson_k")) {
+    NSK_REQUIRE(value >= 0 && value <= 8, "poisson_k must be 0 (default) .. 8, got %d", value);
+    ctx->poisson_k = value;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_rows")) {
+    NSK_REQUIRE(value >= 0, "poisson_rows must be >= 0, got %d", value);
+    ctx->poisson_rows = value;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_div")) {
+    NSK_REQUIRE(value == -1 || value == 0 || value == 3 || value == 4,
+                "poisson_div must be -1 (automatic), 0, 3 or 4, got %d", value);
+    ctx->poisson_div = value;
+    return 0;
+  }
+  nsk_set_error("nsk_set_option: unknown option '%s'", name);
+  return 2;
+}
+
+extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
+  NSK_REQUIRE(ctx != nullptr && name != nullptr && value != nullptr, "nsk_get_option: null argument");
+  if (!strcmp(name, "poisson_k")) {
+    *value = ctx->poisson_k > 0 ? ctx->poisson_k : NSK_DEFAULT_POISSON_K;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_rows")) {
+    *value = ctx->poisson_rows;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_div")) {
+    *value = ctx->poisson_div;
+    return 0;
+  }
+  nsk_set_error("nsk_get_option: unknown option '%s'", name);
+  return 2;
 }
 
 extern "C" int nsk_sync(nsk_ctx *ctx) {

@@ -8,6 +8,8 @@
 
 #include "../../include/nsk.h"
 
+#define NSK_DEFAULT_POISSON_K 4
+
 struct nsk_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -20,7 +22,9 @@ struct nsk_ctx {
   // (re)allocated on demand by the fused entry points.
   double *pp_pr = nullptr, *pp_dp = nullptr;
   size_t pp_elems = 0;
-  int poisson_k = 0;  // 0 = library default; set by NSK_POISSON_K / nsk_set_option
+  int poisson_k = 0;     // passes per launch, 0 = NSK_DEFAULT_POISSON_K (NSK_POISSON_K / nsk_set_option)
+  int poisson_div = -1;  // -1 = automatic; 0 / 3 / 4 force a division form (testing)
+  int poisson_rows = 0;  // rows per task chunk, 0 = automatic (NSK_POISSON_ROWS / nsk_set_option)
 };
 
 void nsk_set_error(const char *fmt, ...);

@@ -121,3 +121,38 @@ def test_poisson_slab_windows(gpu, oracle):
                 assert same_bits(gPr[:, 0], wPr[:, 0])
             if hi < nyg:
                 assert same_bits(gPr[:, -1], wPr[:, -1])
+
+
+@pytest.mark.parametrize("div", [0, 3, 4])
+def test_poisson_division_forms(oracle, div):
+    """x/dx/dx is evaluated either by IEEE division or by an FMA sequence that yields the same
+    correctly rounded quotient.  Forced forms on: ordinary data, data near the underflow range
+    (where the FMA form must hand over to IEEE division), exact zeros, and huge values."""
+    import torch
+    from navierstokes_amd import _lib
+    ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    ctx.set_option("poisson_div", div)
+    try:
+        nx, ny = 153, 255
+        p = ns_params("NavierStokes")
+        rng = np.random.default_rng(100 + div)
+        for scale, zero_frac in [(1.0, 0.0), (1e-290, 0.0), (1e-305, 0.3), (1e-318, 0.5), (1.0, 0.7), (1e290, 0.0)]:
+            Pr0 = rng_field(rng, nx, ny, scale)
+            dP0 = rng_field(rng, nx - 2, ny - 2, scale)
+            dv = rng_field(rng, nx, ny, scale)
+            if zero_frac:
+                Pr0[rng.random((nx, ny)) < zero_frac] = 0.0
+                Pr0[:, ny // 2:] = 0.0
+                dP0[:, ny // 2:] = 0.0
+                dv[:, ny // 2:] = 0.0
+            for pitched in (False, True):
+                Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
+                with np.errstate(all="ignore"):
+                    oracle_iters(oracle, p, Pr, dP, dv, 9, 0)
+                gPr, gdP = run_gpu(ctx, p, Pr0, dP0, dv, 9, 0, pitched)
+                if scale < 1e200:
+                    assert np.isfinite(Pr).all()
+                assert same_bits(gPr, Pr), (scale, zero_frac, pitched)
+                assert same_bits(gdP, dP), (scale, zero_frac, pitched)
+    finally:
+        ctx.close()
