@@ -1,0 +1,71 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/nsk.h declares, and the
+Python binding's structs match the header.  No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared():
+    names = []
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if h.endswith(".h"):
+            text = open(os.path.join(ROOT, "include", h)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            names += re.findall(r"\b(nsk_[a-z0-9_A-Z]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_every_declared_symbol_is_exported():
+    from navierstokes_amd import _lib
+    lib = _lib.load()
+    names = declared()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    # ... and the binding knows every one of them
+    unbound = [n for n in names if n not in _lib.exported_names()]
+    assert not unbound, unbound
+
+
+def test_struct_layout_matches_header():
+    from navierstokes_amd import _lib
+    text = open(os.path.join(ROOT, "include", "nsk.h")).read()
+    body = re.search(r"typedef struct nsk_ns_params \{(.*?)\} nsk_ns_params;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            ty, rest = decl.split(None, 1)
+            fields += [(n.strip(), ty) for n in rest.split(",")]
+    want = [(n, {"int": C.c_int, "double": C.c_double}[t]) for n, t in fields]
+    assert [(n, t) for n, t in _lib.CNSParams._fields_] == want
+    body = re.search(r"typedef struct nsk_ns_state \{(.*?)\} nsk_ns_state;", text, re.S).group(1)
+    names = [n.strip(" *\n") for n in body.replace("double", "").replace(";", "").split(",")]
+    assert [n for n, _ in _lib.CNSState._fields_] == names
+
+
+def test_no_gpu_is_an_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU")
+    from navierstokes_amd import _lib
+    from navierstokes_amd.ns import NavierStokes
+    from navierstokes_amd import ns_params
+    with pytest.raises(_lib.NskError):
+        _lib.Context(0)
+    with pytest.raises(_lib.NskError):
+        NavierStokes(ns_params("NavierStokes", nx=9, ny=15))
+
+
+def test_product_package_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "navierstokes_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("oracle's", "") or f == "dist.py", (dirpath, f)
