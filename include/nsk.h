@@ -185,6 +185,86 @@ int nsk_ns_step(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_params *p,
                 int *iters_out, double *err_hist, int *iter_hist, int hist_cap,
                 int *nhist_out);
 
+/* ---- bubble / drop solvers: scripts/DNS.jl (= scripts/code1.m) and scripts/code3_fun.jl ---
+ * Grid arrays are (nx+2) x (ny+2) with one ghost layer; u is (nx+1) x (ny+2), v is
+ * (nx+2) x (ny+1); fronts are vectors with points 2..Nf+1 and two periodic ghost points
+ * (1-based).  DNS.jl does not run as written (undefined variables, statements cut by line
+ * breaks); these entry points implement the algorithm it transcribes, scripts/code1.m:33-101. */
+
+/* set_density!  DNS.jl:128-137 / code1.m:25-28; with m != NULL also set_density_viscosity!
+ * code3_fun.jl:8-18.  x, y: cell-centre coordinates (nx+2), (ny+2). */
+int nsk_bub_set_density(nsk_ctx *ctx, double *r, double *m, double xc, double yc,
+                        const double *x, const double *y, double rad, double rho2,
+                        double m2, int nx, int ny);
+/* set_tangential!  DNS.jl:118-126 / code1.m:33-34 / code3_fun.jl:28-35 */
+int nsk_bub_set_tangential(nsk_ctx *ctx, double *u, double *v, double usouth,
+                           double unorth, double vwest, double veast, int nx, int ny);
+/* temp_uvel! + temp_vvel!  DNS.jl:159-179 / code1.m:36-52 (ut or vt may be NULL) */
+int nsk_bub_temp_vel(nsk_ctx *ctx, double *ut, double *vt, const double *u,
+                     const double *v, const double *r, double dt, double dx, double dy,
+                     double gx, double gy, double m0, int nx, int ny);
+/* temp_uvel_adv! + temp_vvel_adv!  code3_fun.jl:37-62 */
+int nsk_bub_temp_vel_adv(nsk_ctx *ctx, double *ut, double *vt, const double *u,
+                         const double *v, const double *r, double dt, double dx,
+                         double dy, const double *fx, const double *fy, double gx,
+                         double gy, double rro, int nx, int ny);
+/* temp_uvel_diff! + temp_vvel_diff!  code3_fun.jl:64-90 */
+int nsk_bub_temp_vel_diff(nsk_ctx *ctx, double *ut, double *vt, const double *u,
+                          const double *v, const double *r, double dt, double dx,
+                          double dy, const double *m, int nx, int ny);
+/* set_boundary!  DNS.jl:138-148 / code1.m:55-57 / code3_fun.jl:415-420: rt = r, lrg on borders */
+int nsk_bub_set_boundary(nsk_ctx *ctx, double *rt, const double *r, double lrg, int nx, int ny);
+/* compute_source!  DNS.jl:149-157 / code1.m:59-65 / code3_fun.jl:92-102 */
+int nsk_bub_compute_sources(nsk_ctx *ctx, double *tmp1, double *tmp2, const double *rt,
+                            const double *ut, const double *vt, double dt, double dx,
+                            double dy, int nx, int ny);
+/* solve_pressure! with its iteration loop and stopping test  DNS.jl:83-93,181-189 /
+ * code1.m:68-78 / code3_fun.jl:104-124.  Lexicographic in-place SOR; returns the sweeps
+ * performed and the last max|old-new|.  Synchronous when an output pointer is given. */
+int nsk_bub_solve_pressure(nsk_ctx *ctx, double *p, const double *tmp1,
+                           const double *tmp2, const double *rt, double beta, double dx,
+                           double dy, int nx, int ny, int maxit, double maxError,
+                           int *sweeps_out, double *change_out);
+/* correct_uvel! + correct_vvel!  DNS.jl:190-202 / code1.m:80-86 (u or v may be NULL) */
+int nsk_bub_correct_vel(nsk_ctx *ctx, double *u, double *v, const double *ut,
+                        const double *vt, const double *p, const double *r, double dt,
+                        double dx, double dy, int nx, int ny);
+/* advect_density!  DNS.jl:204-212 as code1.m:88-96 states it */
+int nsk_bub_advect_density(nsk_ctx *ctx, double *r, const double *ro, const double *u,
+                           const double *v, double dt, double dx, double dy, double m0,
+                           int nx, int ny);
+/* velocity!  DNS.jl:214-220 / code1.m:100-101 (all (nx+1) x (ny+1) corner values) */
+int nsk_bub_velocity(nsk_ctx *ctx, double *uu, double *vv, const double *u,
+                     const double *v, int nx, int ny);
+/* surface tension: tangents code3_fun.jl:372-378, spreading :365-366,380-401 */
+int nsk_bub_surface_tension(nsk_ctx *ctx, double *fx, double *fy, double *tx, double *ty,
+                            const double *xf, const double *yf, double sigma, double dx,
+                            double dy, int nx, int ny, int Nf);
+/* advect_front! + move_front!  code3_fun.jl:144-195; out_of_bounds (may be NULL) counts the
+ * points the reference would print a warning for */
+int nsk_bub_advect_move_front(nsk_ctx *ctx, double *uf, double *vf, double *xf, double *yf,
+                              const double *u, const double *v, double dx, double dy,
+                              double dt, double Lx, double Ly, int nx, int ny, int Nf,
+                              int *out_of_bounds);
+/* fx = fy = 0 and distribute!  code3_fun.jl:433-435,197-222 */
+int nsk_bub_distribute(nsk_ctx *ctx, double *fx, double *fy, const double *xf,
+                       const double *yf, double rho1, double rho2, double dx, double dy,
+                       int nx, int ny, int Nf);
+/* construct_den!  code3_fun.jl:224-240 */
+int nsk_bub_construct_den(nsk_ctx *ctx, double *r, const double *fx, const double *fy,
+                          double beta, int maxit, double maxError, double dx, double dy,
+                          int nx, int ny, int *sweeps_out);
+/* m = m1 and update_visco!  code3_fun.jl:440-441,242-249 */
+int nsk_bub_update_visco(nsk_ctx *ctx, const double *r, double *m, double m1, double m2,
+                         double rho1, double rho2, int nx, int ny);
+/* a = 0.5*(a + b)  code3_fun.jl:445-450 */
+int nsk_bub_average(nsk_ctx *ctx, double *a, const double *b, size_t count);
+/* front regridding  code3_fun.jl:455-494; xf, yf and the two scratch vectors hold `cap`
+ * points; an error is returned where the reference would resize its vectors. Synchronous. */
+int nsk_bub_regrid_front(nsk_ctx *ctx, double *xf, double *yf, double *xscratch,
+                         double *yscratch, double dx, double dy, int Nf, int cap,
+                         int *Nf_out);
+
 #ifdef __cplusplus
 }
 #endif

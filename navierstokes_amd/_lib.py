@@ -66,6 +66,25 @@ _SIGS = {
     "nsk_set_option": [C.c_char_p, _I],
     "nsk_get_option": [C.c_char_p, c_int_p],
     "nsk_sync": [],
+    # bubble / drop solvers
+    "nsk_bub_set_density": [_P, _P, _D, _D, _P, _P, _D, _D, _D, _I, _I],
+    "nsk_bub_set_tangential": [_P, _P, _D, _D, _D, _D, _I, _I],
+    "nsk_bub_temp_vel": [_P, _P, _P, _P, _P, _D, _D, _D, _D, _D, _D, _I, _I],
+    "nsk_bub_temp_vel_adv": [_P, _P, _P, _P, _P, _D, _D, _D, _P, _P, _D, _D, _D, _I, _I],
+    "nsk_bub_temp_vel_diff": [_P, _P, _P, _P, _P, _D, _D, _D, _P, _I, _I],
+    "nsk_bub_set_boundary": [_P, _P, _D, _I, _I],
+    "nsk_bub_compute_sources": [_P, _P, _P, _P, _P, _D, _D, _D, _I, _I],
+    "nsk_bub_solve_pressure": [_P, _P, _P, _P, _D, _D, _D, _I, _I, _I, _D, c_int_p, c_double_p],
+    "nsk_bub_correct_vel": [_P, _P, _P, _P, _P, _P, _D, _D, _D, _I, _I],
+    "nsk_bub_advect_density": [_P, _P, _P, _P, _D, _D, _D, _D, _I, _I],
+    "nsk_bub_velocity": [_P, _P, _P, _P, _I, _I],
+    "nsk_bub_surface_tension": [_P, _P, _P, _P, _P, _P, _D, _D, _D, _I, _I, _I],
+    "nsk_bub_advect_move_front": [_P, _P, _P, _P, _P, _P, _D, _D, _D, _D, _D, _I, _I, _I, c_int_p],
+    "nsk_bub_distribute": [_P, _P, _P, _P, _D, _D, _D, _D, _I, _I, _I],
+    "nsk_bub_construct_den": [_P, _P, _P, _D, _I, _D, _D, _D, _I, _I, c_int_p],
+    "nsk_bub_update_visco": [_P, _P, _D, _D, _D, _D, _I, _I],
+    "nsk_bub_average": [_P, _P, _S],
+    "nsk_bub_regrid_front": [_P, _P, _P, _P, _D, _D, _I, _I, c_int_p],
     "nsk_ns_poisson_iters": [_P, _P, _P, C.POINTER(CNSParams), _I],
     "nsk_ns_residual": [_P, _P, _P, C.POINTER(CNSParams), _I, _I, c_double_p],
     "nsk_ns_poisson": [_P, _P, _P, _P, C.POINTER(CNSParams), c_int_p, c_double_p, c_int_p, _I, c_int_p],

@@ -1,0 +1,283 @@
+"""Host drivers of the bubble / drop solvers on libnsk.
+
+DNS       mirrors ``main(; do_vis, do_save)`` of /root/reference/scripts/DNS.jl:14-116 (parameters
+          :16-41, allocation :52-62, loop :70-113).  DNS.jl does not run as written; the kernels
+          called are the algorithm it transcribes, scripts/code1.m:33-101.
+Code3     mirrors the script body of /root/reference/scripts/code3_fun.jl:296-494.
+PyTorch provides device memory and the stream only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class DArr:
+    """Column-major (n1 x n2) Float64 device array (n2 = 1 for vectors)."""
+
+    def __init__(self, n1: int, n2: int = 1, device="cuda:0", fill: float = 0.0):
+        self.n1, self.n2 = n1, n2
+        self.t = torch.full((n2, n1), fill, dtype=torch.float64, device=device)
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.t.data_ptr())
+
+    def set(self, host: np.ndarray) -> None:
+        host = np.asarray(host, dtype=np.float64).reshape(self.n1, self.n2, order="F")
+        self.t.copy_(torch.from_numpy(np.ascontiguousarray(host.T)))
+
+    def get(self) -> np.ndarray:
+        a = np.asfortranarray(self.t.cpu().numpy().T)
+        return a[:, 0].copy() if self.n2 == 1 else a
+
+    def copy_from(self, other: "DArr") -> None:
+        self.t.copy_(other.t)
+
+
+@dataclass
+class DNSParams:
+    """DNS.jl:16-45 (code1.m:8-13 has maxit=200)."""
+    Lx: float = 1.0
+    Ly: float = 1.0
+    gx: float = 0.0
+    gy: float = -100.0
+    rho1: float = 1.0
+    rho2: float = 2.0
+    m0: float = 0.01
+    unorth: float = 0.0
+    usouth: float = 0.0
+    veast: float = 0.0
+    vwest: float = 0.0
+    rad: float = 0.15
+    xcenter: float = 0.5
+    ycenter: float = 0.7
+    nx: int = 32
+    ny: int = 32
+    dt: float = 0.00125
+    nsteps: int = 100
+    nvis: int = 10
+    maxit: int = 400
+    maxerr: float = 1e-3
+    beta: float = 1.2
+
+    @property
+    def dx(self):
+        return self.Lx / self.nx
+
+    @property
+    def dy(self):
+        return self.Ly / self.ny
+
+
+def _ctx(device):
+    if not torch.cuda.is_available():
+        raise _lib.NskError("no GPU visible: the bubble drivers have no CPU path")
+    dev = torch.device(device)
+    torch.cuda.set_device(dev)
+    return dev, _lib.Context(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
+
+
+def cell_centres(n: int, d: float) -> np.ndarray:
+    """x(i) = d*(i-1.5), i = 1..n+2 (code1.m:22, code3_fun.jl:328-329)."""
+    return np.array([d * (i - 1.5) for i in range(1, n + 3)])
+
+
+class DNS:
+    """State and time step of DNS.jl's drop problem."""
+
+    def __init__(self, q: DNSParams = DNSParams(), device: str = "cuda:0"):
+        self.q = q
+        self.dev, self.ctx = _ctx(device)
+        nx, ny, d = q.nx, q.ny, self.dev
+        A = lambda a, b=1, fill=0.0: DArr(a, b, d, fill)
+        # DNS.jl:52-62
+        self.rho, self.rhot, self.rho_o = A(nx + 2, ny + 2, q.rho1), A(nx + 2, ny + 2), A(nx + 2, ny + 2)
+        self.u, self.v, self.p = A(nx + 1, ny + 2), A(nx + 2, ny + 1), A(nx + 2, ny + 2)
+        self.ut, self.vt = A(nx + 1, ny + 2), A(nx + 2, ny + 1)
+        self.uu, self.vv = A(nx + 1, ny + 1), A(nx + 1, ny + 1)
+        self.tmp1, self.tmp2 = A(nx + 2, ny + 2), A(nx + 2, ny + 2)
+        self.xc, self.yc = A(nx + 2), A(ny + 2)
+        self.xc.set(cell_centres(nx, q.dx))
+        self.yc.set(cell_centres(ny, q.dy))
+        # DNS.jl:64-67
+        self.ctx.bub_set_density(self.rho.ptr, None, q.xcenter, q.ycenter, self.xc.ptr, self.yc.ptr,
+                                 q.rad, q.rho2, 0.0, nx, ny)
+        self.time = 0.0
+        self.sweeps = 0
+
+    def step(self) -> int:
+        """DNS.jl:71-101."""
+        q, k, nx, ny = self.q, self.ctx, self.q.nx, self.q.ny
+        self.time += q.dt
+        k.bub_set_tangential(self.u.ptr, self.v.ptr, q.usouth, q.unorth, q.vwest, q.veast, nx, ny)
+        k.bub_temp_vel(self.ut.ptr, self.vt.ptr, self.u.ptr, self.v.ptr, self.rho.ptr, q.dt, q.dx, q.dy,
+                       q.gx, q.gy, q.m0, nx, ny)
+        k.bub_set_boundary(self.rhot.ptr, self.rho.ptr, 1000.0, nx, ny)
+        k.bub_compute_sources(self.tmp1.ptr, self.tmp2.ptr, self.rhot.ptr, self.ut.ptr, self.vt.ptr,
+                              q.dt, q.dx, q.dy, nx, ny)
+        sw = C.c_int(0)
+        k.bub_solve_pressure(self.p.ptr, self.tmp1.ptr, self.tmp2.ptr, self.rhot.ptr, q.beta, q.dx, q.dy,
+                             nx, ny, q.maxit, q.maxerr, C.byref(sw), None)
+        k.bub_correct_vel(self.u.ptr, self.v.ptr, self.ut.ptr, self.vt.ptr, self.p.ptr, self.rho.ptr,
+                          q.dt, q.dx, q.dy, nx, ny)
+        self.rho_o.copy_from(self.rho)
+        k.bub_advect_density(self.rho.ptr, self.rho_o.ptr, self.u.ptr, self.v.ptr, q.dt, q.dx, q.dy, q.m0, nx, ny)
+        k.bub_velocity(self.uu.ptr, self.vv.ptr, self.u.ptr, self.v.ptr, nx, ny)
+        self.sweeps = sw.value
+        return sw.value
+
+
+def dns_main(do_vis: bool = True, do_save: bool = False, *, q: DNSParams = DNSParams(),
+             device: str = "cuda:0", out_dir: str = "out_dns", verbose: bool = True) -> DNS:
+    """`main(; do_vis, do_save)` of DNS.jl; saves Vx, Vy, C, dx, dy like DNS.jl:63,105."""
+    from scipy.io import savemat
+    sim = DNS(q, device)
+    nstep = 1
+    for it in range(1, q.nsteps + 1):
+        sim.step()
+        if it % q.nvis == 0:
+            if do_save:
+                os.makedirs(out_dir, exist_ok=True)
+                savemat(os.path.join(out_dir, f"step_{nstep}.mat"),
+                        {"Vx": sim.uu.get(), "Vy": sim.vv.get(), "C": sim.rho.get(), "dx": q.dx, "dy": q.dy})
+                nstep += 1
+            if verbose:
+                print(f"time = {sim.time}")
+    return sim
+
+
+@dataclass
+class Code3Params:
+    """code3_fun.jl:296-309,337,340."""
+    Lx: float = 1.0
+    Ly: float = 1.0
+    gx: float = 0.0
+    gy: float = -100.0
+    rho1: float = 1.0
+    rho2: float = 2.0
+    m1: float = 0.01
+    m2: float = 0.05
+    sigma: float = 10.0
+    unorth: float = 0.0
+    usouth: float = 0.0
+    veast: float = 0.0
+    vwest: float = 0.0
+    rad: float = 0.15
+    xc: float = 0.5
+    yc: float = 0.7
+    nx: int = 32
+    ny: int = 32
+    dt0: float = 0.00125
+    nstep: int = 300
+    maxit: int = 200
+    maxError: float = 0.001
+    beta: float = 1.2
+    Nf: int = 100
+    cap: int = 1024         # capacity of the front vectors (the reference resizes on demand)
+
+    @property
+    def rro(self):
+        return self.rho1
+
+    @property
+    def dx(self):
+        return self.Lx / self.nx
+
+    @property
+    def dy(self):
+        return self.Ly / self.ny
+
+    @property
+    def dt(self):
+        # code3_fun.jl:337 with m == m1 everywhere at that point
+        return min(self.dt0, 0.25 * min(self.dx, self.dy) ** 2 * min(self.rho1, self.rho2) / self.m1)
+
+
+def front_circle(q: Code3Params):
+    """set_front!, code3_fun.jl:20-26."""
+    l = np.arange(q.Nf + 2)
+    xf = np.array([q.xc - q.rad * math.sin(2.0 * math.pi * i / q.Nf) for i in l])
+    yf = np.array([q.yc + q.rad * math.cos(2.0 * math.pi * i / q.Nf) for i in l])
+    return xf, yf
+
+
+class Code3:
+    """State and time step of code3_fun.jl."""
+
+    GRID = ("u", "v", "p", "ut", "vt", "tmp1", "tmp2", "fx", "fy", "un", "vn", "r", "m", "rn", "mn", "rt")
+    FRONT = ("xf", "yf", "xfn", "yfn", "uf", "vf", "tx", "ty", "xs", "ys")
+
+    def __init__(self, q: Code3Params = Code3Params(), device: str = "cuda:0"):
+        self.q = q
+        self.dev, self.ctx = _ctx(device)
+        nx, ny, d = q.nx, q.ny, self.dev
+        shp = dict(u=(nx + 1, ny + 2), v=(nx + 2, ny + 1), ut=(nx + 1, ny + 2), vt=(nx + 2, ny + 1),
+                   un=(nx + 1, ny + 2), vn=(nx + 2, ny + 1))
+        for k in self.GRID:
+            setattr(self, k, DArr(*shp.get(k, (nx + 2, ny + 2)), d))
+        self.r.t.fill_(q.rho1)       # code3_fun.jl:332-333
+        self.m.t.fill_(q.m1)
+        for k in self.FRONT:
+            setattr(self, k, DArr(q.cap, 1, d))
+        xf, yf = front_circle(q)
+        pad = np.zeros(q.cap)
+        pad[: q.Nf + 2] = xf
+        self.xf.set(pad)
+        pad = np.zeros(q.cap)
+        pad[: q.Nf + 2] = yf
+        self.yf.set(pad)
+        self.Nf = q.Nf
+        self.time = 0.0
+        self.sweeps = [0, 0, 0, 0]
+
+    def step(self):
+        """code3_fun.jl:356-494."""
+        q, k, nx, ny = self.q, self.ctx, self.q.nx, self.q.ny
+        dt, dx, dy = q.dt, q.dx, q.dy
+        for a, b in (("un", "u"), ("vn", "v"), ("rn", "r"), ("mn", "m"), ("xfn", "xf"), ("yfn", "yf")):
+            getattr(self, a).copy_from(getattr(self, b))
+        sw = [0, 0, 0, 0]
+        for sub in range(2):
+            k.bub_surface_tension(self.fx.ptr, self.fy.ptr, self.tx.ptr, self.ty.ptr, self.xf.ptr, self.yf.ptr,
+                                  q.sigma, dx, dy, nx, ny, self.Nf)
+            k.bub_set_tangential(self.u.ptr, self.v.ptr, q.usouth, q.unorth, q.vwest, q.veast, nx, ny)
+            k.bub_temp_vel_adv(self.ut.ptr, self.vt.ptr, self.u.ptr, self.v.ptr, self.r.ptr, dt, dx, dy,
+                               self.fx.ptr, self.fy.ptr, q.gx, q.gy, q.rro, nx, ny)
+            k.bub_temp_vel_diff(self.ut.ptr, self.vt.ptr, self.u.ptr, self.v.ptr, self.r.ptr, dt, dx, dy,
+                                self.m.ptr, nx, ny)
+            k.bub_set_boundary(self.rt.ptr, self.r.ptr, 1000.0, nx, ny)
+            k.bub_compute_sources(self.tmp1.ptr, self.tmp2.ptr, self.rt.ptr, self.ut.ptr, self.vt.ptr, dt, dx, dy, nx, ny)
+            a = C.c_int(0)
+            k.bub_solve_pressure(self.p.ptr, self.tmp1.ptr, self.tmp2.ptr, self.rt.ptr, q.beta, dx, dy, nx, ny,
+                                 q.maxit, q.maxError, C.byref(a), None)
+            k.bub_correct_vel(self.u.ptr, self.v.ptr, self.ut.ptr, self.vt.ptr, self.p.ptr, self.r.ptr, dt, dx, dy, nx, ny)
+            k.bub_advect_move_front(self.uf.ptr, self.vf.ptr, self.xf.ptr, self.yf.ptr, self.u.ptr, self.v.ptr,
+                                    dx, dy, dt, q.Lx, q.Ly, nx, ny, self.Nf, None)
+            k.bub_distribute(self.fx.ptr, self.fy.ptr, self.xf.ptr, self.yf.ptr, q.rho1, q.rho2, dx, dy, nx, ny, self.Nf)
+            b = C.c_int(0)
+            k.bub_construct_den(self.r.ptr, self.fx.ptr, self.fy.ptr, q.beta, q.maxit, q.maxError, dx, dy, nx, ny, C.byref(b))
+            k.bub_update_visco(self.r.ptr, self.m.ptr, q.m1, q.m2, q.rho1, q.rho2, nx, ny)
+            sw[2 * sub], sw[2 * sub + 1] = a.value, b.value
+        # second-order averaging, code3_fun.jl:445-450
+        for a, b in (("u", "un"), ("v", "vn"), ("r", "rn"), ("m", "mn")):
+            A = getattr(self, a)
+            k.bub_average(A.ptr, getattr(self, b).ptr, A.n1 * A.n2)
+        k.bub_average(self.xf.ptr, self.xfn.ptr, self.Nf + 2)
+        k.bub_average(self.yf.ptr, self.yfn.ptr, self.Nf + 2)
+        nf = C.c_int(0)
+        k.bub_regrid_front(self.xf.ptr, self.yf.ptr, self.xs.ptr, self.ys.ptr, dx, dy, self.Nf, q.cap, C.byref(nf))
+        self.Nf = nf.value
+        self.time += dt
+        self.sweeps = sw
+        return sw
+
+    def front(self):
+        return self.xf.get()[: self.Nf + 2], self.yf.get()[: self.Nf + 2]

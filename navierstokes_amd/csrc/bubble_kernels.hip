@@ -1,0 +1,677 @@
+// Bubble / drop kernels: the constant-viscosity code1 family that scripts/DNS.jl transcribes
+// (ground truth scripts/code1.m:33-101, Julia statement scripts/code1_loop_fun.jl:7-115,
+// kernel split scripts/DNS.jl:118-220) and the front-tracking code3
+// (scripts/code3_fun.jl:8-293, time loop :354-494).
+//
+// Grid arrays are (nx+2) x (ny+2) cell-centred with one ghost layer, u is (nx+1) x (ny+2),
+// v is (nx+2) x (ny+1), column-major, i contiguous.  One thread per grid point, 64 consecutive
+// i per wavefront row.  The two lexicographic Gauss-Seidel/SOR solvers (pressure, density) run
+// in ONE workgroup that sweeps anti-diagonals i+j = const: every cell of a diagonal depends only
+// on the two previous diagonals (new values) and the two next ones (old values), exactly the
+// operands of the reference's in-place i-outer/j-inner loop, so the result is bit-identical; the
+// whole iteration loop with its max|old-new| stopping test stays inside the one launch.
+// The front-to-grid spreading is a gather: each grid point scans the front points in ascending
+// order and adds the contributions that land on it, which reproduces the reference's
+// sequential accumulation order without atomics.
+#include <cmath>
+#include <cstring>
+
+#include "nsk_internal.h"
+
+namespace {
+
+#define B2(a, ld, i, j) (a)[(size_t)((j)-1) * (size_t)(ld) + (size_t)((i)-1)]
+#define SQ(x) ((x) * (x))
+#define U(i, j) B2(u, nx + 1, i, j)
+#define V(i, j) B2(v, nx + 2, i, j)
+#define R(i, j) B2(r, nx + 2, i, j)
+#define M(i, j) B2(m, nx + 2, i, j)
+#define RT(i, j) B2(rt, nx + 2, i, j)
+
+constexpr int BX = 64, BY = 4;
+inline dim3 grid2(int n1, int n2) { return dim3(nsk_cdiv(n1, BX), nsk_cdiv(n2, BY)); }
+inline dim3 block2() { return dim3(BX, BY); }
+#define IJ                                           \
+  const int i = blockIdx.x * BX + threadIdx.x + 1;   \
+  const int j = blockIdx.y * BY + threadIdx.y + 1
+
+typedef const double *__restrict__ cdp;
+typedef double *__restrict__ dp;
+
+// code1.m:25-28 / DNS.jl:128-137 / code3_fun.jl:8-18
+__global__ void k_set_density(dp r, dp m, double xc, double yc, cdp x, cdp y, double rad,
+                              double rho2, double m2, int nx, int ny) {
+  IJ;
+  if (i < 2 || i > nx + 1 || j < 2 || j > ny + 1) return;
+  if (SQ(x[i - 1] - xc) + SQ(y[j - 1] - yc) < SQ(rad)) {
+    R(i, j) = rho2;
+    if (m) M(i, j) = m2;
+  }
+}
+
+// code1.m:33-34 / code3_fun.jl:28-35
+__global__ void k_set_tangential(dp u, dp v, double usouth, double unorth, double vwest,
+                                 double veast, int nx, int ny) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  if (t <= nx + 1) {
+    U(t, 1) = 2 * usouth - U(t, 2);
+    U(t, ny + 2) = 2 * unorth - U(t, ny + 1);
+  }
+  if (t <= ny + 1) {
+    V(1, t) = 2 * vwest - V(2, t);
+    V(nx + 2, t) = 2 * veast - V(nx + 1, t);
+  }
+}
+
+__device__ __forceinline__ double adv_u(cdp u, cdp v, double dx, double dy, int nx, int i, int j) {
+  return -0.25 * ((SQ(U(i + 1, j) + U(i, j)) - SQ(U(i, j) + U(i - 1, j))) / dx +
+                  ((U(i, j + 1) + U(i, j)) * (V(i + 1, j) + V(i, j)) -
+                   (U(i, j) + U(i, j - 1)) * (V(i + 1, j - 1) + V(i, j - 1))) / dy);
+}
+__device__ __forceinline__ double adv_v(cdp u, cdp v, double dx, double dy, int nx, int i, int j) {
+  return -0.25 * (((U(i, j + 1) + U(i, j)) * (V(i + 1, j) + V(i, j)) -
+                   (U(i - 1, j + 1) + U(i - 1, j)) * (V(i, j) + V(i - 1, j))) / dx +
+                  (SQ(V(i, j + 1) + V(i, j)) - SQ(V(i, j) + V(i, j - 1))) / dy);
+}
+
+// code1.m:36-52: both temporary velocities in one launch
+__global__ void k_temp_vel(dp ut, dp vt, cdp u, cdp v, cdp r, double dt, double dx, double dy,
+                           double gx, double gy, double m0, int nx, int ny) {
+  IJ;
+  if (ut && i >= 2 && i <= nx && j >= 2 && j <= ny + 1)
+    B2(ut, nx + 1, i, j) =
+        U(i, j) + dt * (adv_u(u, v, dx, dy, nx, i, j) +
+                        m0 / (0.5 * (R(i + 1, j) + R(i, j))) *
+                            ((U(i + 1, j) - 2 * U(i, j) + U(i - 1, j)) / SQ(dx) +
+                             (U(i, j + 1) - 2 * U(i, j) + U(i, j - 1)) / SQ(dy)) +
+                        gx);
+  if (vt && i >= 2 && i <= nx + 1 && j >= 2 && j <= ny)
+    B2(vt, nx + 2, i, j) =
+        V(i, j) + dt * (adv_v(u, v, dx, dy, nx, i, j) +
+                        m0 / (0.5 * (R(i, j + 1) + R(i, j))) *
+                            ((V(i + 1, j) - 2 * V(i, j) + V(i - 1, j)) / SQ(dx) +
+                             (V(i, j + 1) - 2 * V(i, j) + V(i, j - 1)) / SQ(dy)) +
+                        gy);
+}
+
+// code3_fun.jl:37-62
+__global__ void k_temp_vel_adv(dp ut, dp vt, cdp u, cdp v, cdp r, double dt, double dx, double dy,
+                               cdp fx, cdp fy, double gx, double gy, double rro, int nx, int ny) {
+  IJ;
+  if (ut && i >= 2 && i <= nx && j >= 2 && j <= ny + 1) {
+    const double rb = 0.5 * (R(i + 1, j) + R(i, j));
+    B2(ut, nx + 1, i, j) = U(i, j) + dt * (adv_u(u, v, dx, dy, nx, i, j) + B2(fx, nx + 2, i, j) / rb -
+                                           (1.0 - rro / rb) * gx);
+  }
+  if (vt && i >= 2 && i <= nx + 1 && j >= 2 && j <= ny) {
+    const double rb = 0.5 * (R(i, j + 1) + R(i, j));
+    B2(vt, nx + 2, i, j) = V(i, j) + dt * (adv_v(u, v, dx, dy, nx, i, j) + B2(fy, nx + 2, i, j) / rb -
+                                           (1.0 - rro / rb) * gy);
+  }
+}
+
+// code3_fun.jl:64-90.  The two expressions differ in what the mean density divides, as written
+// in the reference: ut += dt*(T1 + (1/dy)*(X-Y)/rbar);  vt += dt*(T1 + T2)/rbar.
+__global__ void k_temp_vel_diff(dp ut, dp vt, cdp u, cdp v, cdp r, double dt, double dx, double dy,
+                                cdp m, int nx, int ny) {
+  IJ;
+  if (ut && i >= 2 && i <= nx && j >= 2 && j <= ny + 1) {
+    const double t1 = (1. / dx) * 2. * (M(i + 1, j) * (1. / dx) * (U(i + 1, j) - U(i, j)) -
+                                        M(i, j) * (1. / dx) * (U(i, j) - U(i - 1, j)));
+    const double X = 0.25 * (M(i, j) + M(i + 1, j) + M(i + 1, j + 1) + M(i, j + 1)) *
+                     ((1. / dy) * (U(i, j + 1) - U(i, j)) + (1. / dx) * (V(i + 1, j) - V(i, j)));
+    const double Y = 0.25 * (M(i, j) + M(i + 1, j) + M(i + 1, j - 1) + M(i, j - 1)) *
+                     ((1. / dy) * (U(i, j) - U(i, j - 1)) + (1. / dx) * (V(i + 1, j - 1) - V(i, j - 1)));
+    const double t2 = (1. / dy) * (X - Y) / (0.5 * (R(i + 1, j) + R(i, j)));
+    B2(ut, nx + 1, i, j) = B2(ut, nx + 1, i, j) + dt * (t1 + t2);
+  }
+  if (vt && i >= 2 && i <= nx + 1 && j >= 2 && j <= ny) {
+    const double X = 0.25 * (M(i, j) + M(i + 1, j) + M(i + 1, j + 1) + M(i, j + 1)) *
+                     ((1.0 / dy) * (U(i, j + 1) - U(i, j)) + (1.0 / dx) * (V(i + 1, j) - V(i, j)));
+    const double Y = 0.25 * (M(i, j) + M(i, j + 1) + M(i - 1, j + 1) + M(i - 1, j)) *
+                     ((1.0 / dy) * (U(i - 1, j + 1) - U(i - 1, j)) + (1.0 / dx) * (V(i, j) - V(i - 1, j)));
+    const double t1 = (1.0 / dx) * (X - Y);
+    const double t2 = (1.0 / dy) * 2.0 * (M(i, j + 1) * (1.0 / dy) * (V(i, j + 1) - V(i, j)) -
+                                          M(i, j) * (1.0 / dy) * (V(i, j) - V(i, j - 1)));
+    B2(vt, nx + 2, i, j) = B2(vt, nx + 2, i, j) + dt * (t1 + t2) / (0.5 * (R(i, j + 1) + R(i, j)));
+  }
+}
+
+// code1.m:55-57: rt = r with lrg on the four borders
+__global__ void k_set_boundary(dp rt, cdp r, double lrg, int nx, int ny) {
+  IJ;
+  if (i > nx + 2 || j > ny + 2) return;
+  const bool border = i == 1 || i == nx + 2 || j == 1 || j == ny + 2;
+  RT(i, j) = border ? lrg : R(i, j);
+}
+
+// code1.m:59-65 / code3_fun.jl:92-102
+__global__ void k_compute_sources(dp tmp1, dp tmp2, cdp rt, cdp ut, cdp vt, double dt, double dx,
+                                  double dy, int nx, int ny) {
+  IJ;
+  if (i < 2 || i > nx + 1 || j < 2 || j > ny + 1) return;
+  B2(tmp1, nx + 2, i, j) = (0.5 / dt) * ((B2(ut, nx + 1, i, j) - B2(ut, nx + 1, i - 1, j)) / dx +
+                                         (B2(vt, nx + 2, i, j) - B2(vt, nx + 2, i, j - 1)) / dy);
+  B2(tmp2, nx + 2, i, j) =
+      1.0 / ((1.0 / dx) * (1.0 / (dx * (RT(i + 1, j) + RT(i, j))) + 1.0 / (dx * (RT(i - 1, j) + RT(i, j)))) +
+             (1.0 / dy) * (1.0 / (dy * (RT(i, j + 1) + RT(i, j))) + 1.0 / (dy * (RT(i, j - 1) + RT(i, j)))));
+}
+
+// code1.m:80-86
+__global__ void k_correct_vel(dp u, dp v, cdp ut, cdp vt, cdp p, cdp r, double dt, double dx,
+                              double dy, int nx, int ny) {
+  IJ;
+  if (u && i >= 2 && i <= nx && j >= 2 && j <= ny + 1)
+    U(i, j) = B2(ut, nx + 1, i, j) -
+              dt * (2.0 / dx) * (B2(p, nx + 2, i + 1, j) - B2(p, nx + 2, i, j)) / (R(i + 1, j) + R(i, j));
+  if (v && i >= 2 && i <= nx + 1 && j >= 2 && j <= ny)
+    V(i, j) = B2(vt, nx + 2, i, j) -
+              dt * (2.0 / dy) * (B2(p, nx + 2, i, j + 1) - B2(p, nx + 2, i, j)) / (R(i, j + 1) + R(i, j));
+}
+
+// code1.m:88-96
+__global__ void k_advect_density(dp r, cdp ro, cdp u, cdp v, double dt, double dx, double dy,
+                                 double m0, int nx, int ny) {
+  IJ;
+  if (i < 2 || i > nx + 1 || j < 2 || j > ny + 1) return;
+#define RO(i, j) B2(ro, nx + 2, i, j)
+  R(i, j) = RO(i, j) -
+            (0.5 * dt / dx) * (U(i, j) * (RO(i + 1, j) + RO(i, j)) - U(i - 1, j) * (RO(i - 1, j) + RO(i, j))) -
+            (0.5 * dt / dy) * (V(i, j) * (RO(i, j + 1) + RO(i, j)) - V(i, j - 1) * (RO(i, j - 1) + RO(i, j))) +
+            (m0 * dt / dx / dx) * (RO(i + 1, j) - 2.0 * RO(i, j) + RO(i - 1, j)) +
+            (m0 * dt / dy / dy) * (RO(i, j + 1) - 2.0 * RO(i, j) + RO(i, j - 1));
+#undef RO
+}
+
+// code1.m:100-101 / DNS.jl:214-220
+__global__ void k_velocity(dp uu, dp vv, cdp u, cdp v, int nx, int ny) {
+  IJ;
+  if (i > nx + 1 || j > ny + 1) return;
+  B2(uu, nx + 1, i, j) = 0.5 * (U(i, j + 1) + U(i, j));
+  B2(vv, nx + 1, i, j) = 0.5 * (V(i + 1, j) + V(i, j));
+}
+
+// code3_fun.jl:440-441 + :242-249
+__global__ void k_update_visco(cdp r, dp m, double m1, double m2, double rho1, double rho2, int nx,
+                               int ny) {
+  IJ;
+  if (i > nx + 2 || j > ny + 2) return;
+  const bool inner = i >= 2 && i <= nx + 1 && j >= 2 && j <= ny + 1;
+  M(i, j) = inner ? m1 + (m2 - m1) * (R(i, j) - rho1) / (rho2 - rho1) : 0.0 + m1;
+}
+
+// code3_fun.jl:445-450: a = 0.5*(a + b)
+__global__ void k_average(dp a, cdp b, size_t n) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) a[k] = 0.5 * (a[k] + b[k]);
+}
+
+// ---- single-workgroup lexicographic SOR ------------------------------------------------
+// MODE 0: pressure (code1.m:68-78 / code3_fun.jl:104-124); MODE 1: density (code3_fun.jl:224-240).
+// `a` is the unknown ((nx+2)x(ny+2), updated in place).  LDS copy of `a` when USE_LDS.
+struct SorArgs {
+  double *a;
+  const double *c1, *c2, *c3;  // pressure: tmp1, tmp2, rt;  density: fx, fy, unused
+  double beta, dx, dy, maxError;
+  int nx, ny, maxit;
+  int *sweeps_out;             // sweeps performed
+  double *change_out;          // last max|old-new|
+};
+
+template <int MODE, bool USE_LDS>
+__global__ void __launch_bounds__(1024) k_sor(SorArgs A) {
+  extern __shared__ double lds[];
+  __shared__ unsigned long long red[16];
+  __shared__ unsigned long long sweep_max;
+  const int nx = A.nx, ny = A.ny, ld = nx + 2;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const size_t ncell = (size_t)ld * (ny + 2);
+  double *a = USE_LDS ? lds : A.a;
+  if (USE_LDS) {
+    for (size_t k = tid; k < ncell; k += nth) lds[k] = A.a[k];
+    __syncthreads();
+  }
+  const double beta = A.beta, dx = A.dx, dy = A.dy;
+  cdp c1 = A.c1;
+  cdp c2 = A.c2;
+  cdp rt = A.c3;
+  int it = 0;
+  unsigned long long last = 0;
+  for (it = 1; it <= A.maxit; it++) {
+    unsigned long long mymax = 0;
+    // anti-diagonals d = i + j, i, j in 2..n+1
+    for (int d = 4; d <= nx + ny + 2; d++) {
+      const int ilo = max(2, d - (ny + 1)), ihi = min(nx + 1, d - 2);
+      for (int i = ilo + tid; i <= ihi; i += nth) {
+        const int j = d - i;
+        const double old = B2(a, ld, i, j);
+        double nw;
+        if (MODE == 0) {
+          nw = (1.0 - beta) * old +
+               beta * B2(c2, ld, i, j) *
+                   ((1.0 / dx) * (B2(a, ld, i + 1, j) / (dx * (RT(i + 1, j) + RT(i, j))) +
+                                  B2(a, ld, i - 1, j) / (dx * (RT(i - 1, j) + RT(i, j)))) +
+                    (1.0 / dy) * (B2(a, ld, i, j + 1) / (dy * (RT(i, j + 1) + RT(i, j))) +
+                                  B2(a, ld, i, j - 1) / (dy * (RT(i, j - 1) + RT(i, j)))) -
+                    B2(c1, ld, i, j));
+        } else {
+          nw = (1.0 - beta) * old +
+               beta * (0.25 * (B2(a, ld, i + 1, j) + B2(a, ld, i - 1, j) + B2(a, ld, i, j + 1) +
+                               B2(a, ld, i, j - 1) + dx * B2(c1, ld, i - 1, j) - dx * B2(c1, ld, i, j) +
+                               dy * B2(c2, ld, i, j - 1) - dy * B2(c2, ld, i, j)));
+        }
+        B2(a, ld, i, j) = nw;
+        const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(old - nw));
+        mymax = b > mymax ? b : mymax;
+      }
+      __syncthreads();  // also makes the stores visible to the workgroup (global or LDS)
+    }
+    // maximum(abs.(old .- new)) over the whole array (ghost cells do not change): integer
+    // max of the bit patterns keeps NaN like Julia's maximum
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_xor(mymax, off, 64);
+      mymax = o > mymax ? o : mymax;
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = mymax;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long m = 0;
+      for (int w = 0; w < (nth + 63) / 64; w++) m = red[w] > m ? red[w] : m;
+      sweep_max = m;
+    }
+    __syncthreads();
+    last = sweep_max;
+    const double ch = __longlong_as_double((long long)last);
+    if (ch < A.maxError) break;  // false for NaN: keeps sweeping, as the reference does
+  }
+  if (USE_LDS) {
+    __syncthreads();
+    for (size_t k = tid; k < ncell; k += nth) A.a[k] = lds[k];
+  }
+  if (tid == 0) {
+    if (A.sweeps_out) *A.sweeps_out = it > A.maxit ? A.maxit : it;
+    if (A.change_out) *A.change_out = __longlong_as_double((long long)last);
+  }
+}
+
+// ---- front kernels ----------------------------------------------------------------------
+
+// code3_fun.jl:372-378: tangents of segments l = 1..Nf+1 (1-based), then tx[Nf+2] = tx[2]
+__global__ void k_front_tangents(dp tx, dp ty, cdp xf, cdp yf, int Nf) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  if (l <= Nf + 1) {
+    const double ex = xf[l] - xf[l - 1], ey = yf[l] - yf[l - 1];
+    const double ds = sqrt(SQ(ex) + SQ(ey));
+    tx[l - 1] = ex / ds;
+    ty[l - 1] = ey / ds;
+  }
+  if (l == Nf + 2) {  // same quantities as l = 2, recomputed to avoid a second launch
+    const double ex = xf[2] - xf[1], ey = yf[2] - yf[1];
+    const double ds = sqrt(SQ(ex) + SQ(ey));
+    tx[Nf + 1] = ex / ds;
+    ty[Nf + 1] = ey / ds;
+  }
+}
+
+// Spreading as a gather (code3_fun.jl:380-401 for KIND 0, :197-222 for KIND 1): grid point
+// (i,j) of fx / fy sums, for l ascending, the weight with which front point l lands on it.
+template <int KIND>
+__global__ void k_spread(dp fx, dp fy, cdp xf, cdp yf, cdp tx, cdp ty, double c0, double c1,
+                         double dx, double dy, int nx, int ny, int Nf) {
+  IJ;
+  if (i > nx + 2 || j > ny + 2) return;
+  double sx = 0.0, sy = 0.0;
+  for (int l = 2; l <= Nf + 1; l++) {
+    const double xl = xf[l - 1], yl = yf[l - 1];
+    double nfx, nfy;
+    if (KIND == 0) {  // surface tension, c0 = sigma
+      nfx = c0 * (tx[l - 1] - tx[l - 2]);
+      nfy = c0 * (ty[l - 1] - ty[l - 2]);
+    } else {          // density jump, c0 = rho1, c1 = rho2
+      nfx = -0.5 * (yf[l] - yf[l - 2]) * (c1 - c0);
+      nfy = 0.5 * (xf[l] - xf[l - 2]) * (c1 - c0);
+    }
+    {
+      const int ip = (int)floor(xl / dx) + 1, jp = (int)floor((yl + 0.5 * dy) / dy) + 1;
+      if ((i == ip || i == ip + 1) && (j == jp || j == jp + 1)) {
+        const double ax = xl / dx - ip + 1, ay = (yl + 0.5 * dy) / dy - jp + 1;
+        const double wx = i == ip ? 1.0 - ax : ax, wy = j == jp ? 1.0 - ay : ay;
+        sx = sx + wx * wy * nfx / dx / dy;
+      }
+    }
+    {
+      const int ip = (int)floor((xl + 0.5 * dx) / dx) + 1, jp = (int)floor(yl / dy) + 1;
+      if ((i == ip || i == ip + 1) && (j == jp || j == jp + 1)) {
+        const double ax = (xl + 0.5 * dx) / dx - ip + 1, ay = yl / dy - jp + 1;
+        const double wx = i == ip ? 1.0 - ax : ax, wy = j == jp ? 1.0 - ay : ay;
+        sy = sy + wx * wy * nfy / dx / dy;
+      }
+    }
+  }
+  B2(fx, nx + 2, i, j) = sx;
+  B2(fy, nx + 2, i, j) = sy;
+}
+
+// code3_fun.jl:144-195: interpolate the velocity to the front and move it; one thread per point,
+// then thread 0 of the last block closes the periodic ghost points.
+__global__ void k_advect_move_front(dp uf, dp vf, dp xf, dp yf, cdp u, cdp v, double dx, double dy,
+                                    double dt, double Lx, double Ly, int nx, int ny, int Nf,
+                                    int *out_count) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x + 2;
+  if (l > Nf + 1) return;
+  const double xl = xf[l - 1], yl = yf[l - 1];
+  // A front point outside the box is an error in the reference (BoundsError); the index clamps
+  // below only keep the loads inside the arrays in that case.
+  int ip = (int)floor(xl / dx) + 1, jp = (int)floor((yl + 0.5 * dy) / dy) + 1;
+  double ax = xl / dx - ip + 1, ay = (yl + 0.5 * dy) / dy - jp + 1;
+  ip = min(max(ip, 1), nx);
+  jp = min(max(jp, 1), ny + 1);
+  double v1 = (1.0 - ax) * (1.0 - ay) * U(ip, jp), v2 = ax * (1.0 - ay) * U(ip + 1, jp);
+  double v3 = (1.0 - ax) * ay * U(ip, jp + 1), v4 = ax * ay * U(ip + 1, jp + 1);
+  const double ufl = v1 + v2 + v3 + v4;
+  ip = (int)floor((xl + 0.5 * dx) / dx) + 1;
+  jp = (int)floor(yl / dy) + 1;
+  ax = (xl + 0.5 * dx) / dx - ip + 1;
+  ay = yl / dy - jp + 1;
+  ip = min(max(ip, 1), nx + 1);
+  jp = min(max(jp, 1), ny);
+  v1 = (1.0 - ax) * (1.0 - ay) * V(ip, jp);
+  v2 = ax * (1.0 - ay) * V(ip + 1, jp);
+  v3 = (1.0 - ax) * ay * V(ip, jp + 1);
+  v4 = ax * ay * V(ip + 1, jp + 1);
+  const double vfl = v1 + v2 + v3 + v4;
+  uf[l - 1] = ufl;
+  vf[l - 1] = vfl;
+  const double xn = xl + dt * ufl, yn = yl + dt * vfl;
+  xf[l - 1] = xn;
+  yf[l - 1] = yn;
+  if (out_count && (xn < 0.0 || xn > Lx || yn < 0.0 || yn > Ly)) atomicAdd(out_count, 1);
+}
+
+__global__ void k_close_front(dp xf, dp yf, int Nf) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    xf[0] = xf[Nf];
+    yf[0] = yf[Nf];
+    xf[Nf + 1] = xf[1];
+    yf[Nf + 1] = yf[1];
+  }
+}
+
+// code3_fun.jl:455-494: regridding reads points it has just written, so it is one thread.
+// xo/yo: scratch copies of the old front.  *Nf_io is updated; -1 signals cap exceeded.
+__global__ void k_regrid_front(dp xf, dp yf, dp xo, dp yo, double dx, double dy, int *Nf_io, int cap) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int Nf = *Nf_io;
+  for (int k = 0; k < Nf + 2; k++) {
+    xo[k] = xf[k];
+    yo[k] = yf[k];
+  }
+  int j = 1;
+  bool ok = true;
+  for (int l = 2; l <= Nf + 1 && ok; l++) {
+    const double ds = sqrt(SQ((xo[l - 1] - xf[j - 1]) / dx) + SQ((yo[l - 1] - yf[j - 1]) / dy));
+    if (ds > 0.5) {
+      j += 1;
+      if (j + 2 > cap) { ok = false; break; }
+      xf[j - 1] = 0.5 * (xo[l - 1] + xf[j - 2]);
+      yf[j - 1] = 0.5 * (yo[l - 1] + yf[j - 2]);
+      j += 1;
+      xf[j - 1] = xo[l - 1];
+      yf[j - 1] = yo[l - 1];
+    } else if (ds < 0.25) {
+    } else {
+      j += 1;
+      if (j + 1 > cap) { ok = false; break; }
+      xf[j - 1] = xo[l - 1];
+      yf[j - 1] = yo[l - 1];
+    }
+  }
+  if (!ok || j + 1 > cap) {
+    *Nf_io = -1;
+    return;
+  }
+  const int Nn = j - 1;
+  xf[0] = xf[Nn];
+  yf[0] = yf[Nn];
+  xf[Nn + 1] = xf[1];
+  yf[Nn + 1] = yf[1];
+  *Nf_io = Nn;
+}
+
+int launch_sor(nsk_ctx *ctx, int mode, double *a, const double *c1, const double *c2,
+               const double *c3, double beta, double dx, double dy, int nx, int ny, int maxit,
+               double maxError, int *sweeps, double *change) {
+  // device-side result slots live in the context's reduction scratch (64 bytes)
+  int *d_sweeps = reinterpret_cast<int *>(ctx->red_dev + 2);
+  double *d_change = reinterpret_cast<double *>(ctx->red_dev + 3);
+  SorArgs A{a, c1, c2, c3, beta, dx, dy, maxError, nx, ny, maxit, d_sweeps, d_change};
+  const size_t bytes = sizeof(double) * (size_t)(nx + 2) * (ny + 2);
+  const bool use_lds = bytes <= 128 * 1024;
+  int nth = nx < ny ? nx : ny;
+  nth = ((nth + 63) / 64) * 64;
+  if (nth > 1024) nth = 1024;
+  if (nth < 64) nth = 64;
+  if (use_lds) {
+    if (mode == 0) {
+      NSK_HIP(hipFuncSetAttribute((const void *)k_sor<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      k_sor<0, true><<<1, nth, bytes, ctx->stream>>>(A);
+    } else {
+      NSK_HIP(hipFuncSetAttribute((const void *)k_sor<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      k_sor<1, true><<<1, nth, bytes, ctx->stream>>>(A);
+    }
+  } else {
+    if (mode == 0) k_sor<0, false><<<1, nth, 0, ctx->stream>>>(A);
+    else k_sor<1, false><<<1, nth, 0, ctx->stream>>>(A);
+  }
+  NSK_LAUNCH_CHECK();
+  if (sweeps || change) {
+    NSK_HIP(hipMemcpyAsync(ctx->red_host + 2, ctx->red_dev + 2, 16, hipMemcpyDeviceToHost, ctx->stream));
+    NSK_HIP(hipStreamSynchronize(ctx->stream));
+    if (sweeps) *sweeps = *reinterpret_cast<int *>(ctx->red_host + 2);
+    if (change) *change = *reinterpret_cast<double *>(ctx->red_host + 3);
+  }
+  return 0;
+}
+
+#define NSK_BGRID_OK(nx, ny) \
+  NSK_REQUIRE((nx) >= 2 && (ny) >= 2, "grid too small: nx=%d ny=%d (need >= 2)", (nx), (ny))
+
+}  // namespace
+
+extern "C" int nsk_bub_set_density(nsk_ctx *ctx, double *r, double *m, double xc, double yc,
+                                   const double *x, const double *y, double rad, double rho2,
+                                   double m2, int nx, int ny) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  k_set_density<<<grid2(nx + 2, ny + 2), block2(), 0, ctx->stream>>>(r, m, xc, yc, x, y, rad, rho2, m2, nx, ny);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nsk_bub_set_tangential(nsk_ctx *ctx, double *u, double *v, double usouth,
+                                      double unorth, double vwest, double veast, int nx, int ny) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  const int n = (nx > ny ? nx : ny) + 1;
+  k_set_tangential<<<nsk_cdiv(n, 256), 256, 0, ctx->stream>>>(u, v, usouth, unorth, vwest, veast, nx, ny);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nsk_bub_temp_vel(nsk_ctx *ctx, double *ut, double *vt, const double *u,
+                                const double *v, const double *r, double dt, double dx, double dy,
+                                double gx, double gy, double m0, int nx, int ny) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  k_temp_vel<<<grid2(nx + 1, ny + 1), block2(), 0, ctx->stream>>>(ut, vt, u, v, r, dt, dx, dy, gx, gy, m0, nx, ny);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nsk_bub_temp_vel_adv(nsk_ctx *ctx, double *ut, double *vt, const double *u,
+                                    const double *v, const double *r, double dt, double dx,
+                                    double dy, const double *fx, const double *fy, double gx,
+                                    double gy, double rro, int nx, int ny) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  k_temp_vel_adv<<<grid2(nx + 1, ny + 1), block2(), 0, ctx->stream>>>(ut, vt, u, v, r, dt, dx, dy, fx, fy, gx, gy, rro, nx, ny);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nsk_bub_temp_vel_diff(nsk_ctx *ctx, double *ut, double *vt, const double *u,
+                                     const double *v, const double *r, double dt, double dx,
+                                     double dy, const double *m, int nx, int ny) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  k_temp_vel_diff<<<grid2(nx + 1, ny + 1), block2(), 0, ctx->stream>>>(ut, vt, u, v, r, dt, dx, dy, m, nx, ny);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nsk_bub_set_boundary(nsk_ctx *ctx, double *rt, const double *r, double lrg, int nx, int ny) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  k_set_boundary<<<grid2(nx + 2, ny + 2), block2(), 0, ctx->stream>>>(rt, r, lrg, nx, ny);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nsk_bub_compute_sources(nsk_ctx *ctx, double *tmp1, double *tmp2, const double *rt,
+                                       const double *ut, const double *vt, double dt, double dx,
+                                       double dy, int nx, int ny) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  k_compute_sources<<<grid2(nx + 2, ny + 2), block2(), 0, ctx->stream>>>(tmp1, tmp2, rt, ut, vt, dt, dx, dy, nx, ny);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nsk_bub_solve_pressure(nsk_ctx *ctx, double *p, const double *tmp1,
+                                      const double *tmp2, const double *rt, double beta, double dx,
+                                      double dy, int nx, int ny, int maxit, double maxError,
+                                      int *sweeps_out, double *change_out) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  NSK_REQUIRE(maxit >= 1, "solve_pressure: maxit=%d", maxit);
+  return launch_sor(ctx, 0, p, tmp1, tmp2, rt, beta, dx, dy, nx, ny, maxit, maxError, sweeps_out, change_out);
+}
+
+extern "C" int nsk_bub_construct_den(nsk_ctx *ctx, double *r, const double *fx, const double *fy,
+                                     double beta, int maxit, double maxError, double dx, double dy,
+                                     int nx, int ny, int *sweeps_out) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  NSK_REQUIRE(maxit >= 1, "construct_den: maxit=%d", maxit);
+  return launch_sor(ctx, 1, r, fx, fy, nullptr, beta, dx, dy, nx, ny, maxit, maxError, sweeps_out, nullptr);
+}
+
+extern "C" int nsk_bub_correct_vel(nsk_ctx *ctx, double *u, double *v, const double *ut,
+                                   const double *vt, const double *p, const double *r, double dt,
+                                   double dx, double dy, int nx, int ny) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  k_correct_vel<<<grid2(nx + 1, ny + 1), block2(), 0, ctx->stream>>>(u, v, ut, vt, p, r, dt, dx, dy, nx, ny);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nsk_bub_advect_density(nsk_ctx *ctx, double *r, const double *ro, const double *u,
+                                      const double *v, double dt, double dx, double dy, double m0,
+                                      int nx, int ny) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  k_advect_density<<<grid2(nx + 2, ny + 2), block2(), 0, ctx->stream>>>(r, ro, u, v, dt, dx, dy, m0, nx, ny);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nsk_bub_velocity(nsk_ctx *ctx, double *uu, double *vv, const double *u,
+                                const double *v, int nx, int ny) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  k_velocity<<<grid2(nx + 1, ny + 1), block2(), 0, ctx->stream>>>(uu, vv, u, v, nx, ny);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nsk_bub_update_visco(nsk_ctx *ctx, const double *r, double *m, double m1, double m2,
+                                    double rho1, double rho2, int nx, int ny) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  k_update_visco<<<grid2(nx + 2, ny + 2), block2(), 0, ctx->stream>>>(r, m, m1, m2, rho1, rho2, nx, ny);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nsk_bub_average(nsk_ctx *ctx, double *a, const double *b, size_t count) {
+  NSK_CTX(ctx);
+  if (count) {
+    k_average<<<(unsigned)((count + 255) / 256), 256, 0, ctx->stream>>>(a, b, count);
+    NSK_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int nsk_bub_surface_tension(nsk_ctx *ctx, double *fx, double *fy, double *tx, double *ty,
+                                       const double *xf, const double *yf, double sigma, double dx,
+                                       double dy, int nx, int ny, int Nf) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  NSK_REQUIRE(Nf >= 1, "surface_tension: Nf=%d", Nf);
+  k_front_tangents<<<nsk_cdiv(Nf + 2, 256), 256, 0, ctx->stream>>>(tx, ty, xf, yf, Nf);
+  NSK_LAUNCH_CHECK();
+  k_spread<0><<<grid2(nx + 2, ny + 2), block2(), 0, ctx->stream>>>(fx, fy, xf, yf, tx, ty, sigma, 0.0, dx, dy, nx, ny, Nf);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nsk_bub_distribute(nsk_ctx *ctx, double *fx, double *fy, const double *xf,
+                                  const double *yf, double rho1, double rho2, double dx, double dy,
+                                  int nx, int ny, int Nf) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  NSK_REQUIRE(Nf >= 1, "distribute: Nf=%d", Nf);
+  k_spread<1><<<grid2(nx + 2, ny + 2), block2(), 0, ctx->stream>>>(fx, fy, xf, yf, nullptr, nullptr, rho1, rho2, dx, dy, nx, ny, Nf);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nsk_bub_advect_move_front(nsk_ctx *ctx, double *uf, double *vf, double *xf, double *yf,
+                                         const double *u, const double *v, double dx, double dy,
+                                         double dt, double Lx, double Ly, int nx, int ny, int Nf,
+                                         int *out_of_bounds) {
+  NSK_CTX(ctx);
+  NSK_BGRID_OK(nx, ny);
+  NSK_REQUIRE(Nf >= 1, "advect_move_front: Nf=%d", Nf);
+  int *d_cnt = reinterpret_cast<int *>(ctx->red_dev + 4);
+  if (out_of_bounds) NSK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int), ctx->stream));
+  k_advect_move_front<<<nsk_cdiv(Nf, 256), 256, 0, ctx->stream>>>(uf, vf, xf, yf, u, v, dx, dy, dt, Lx, Ly, nx, ny, Nf,
+                                                                 out_of_bounds ? d_cnt : nullptr);
+  NSK_LAUNCH_CHECK();
+  k_close_front<<<1, 64, 0, ctx->stream>>>(xf, yf, Nf);
+  NSK_LAUNCH_CHECK();
+  if (out_of_bounds) {
+    NSK_HIP(hipMemcpyAsync(ctx->red_host + 4, d_cnt, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    NSK_HIP(hipStreamSynchronize(ctx->stream));
+    *out_of_bounds = *reinterpret_cast<int *>(ctx->red_host + 4);
+  }
+  return 0;
+}
+
+extern "C" int nsk_bub_regrid_front(nsk_ctx *ctx, double *xf, double *yf, double *xscratch,
+                                    double *yscratch, double dx, double dy, int Nf, int cap,
+                                    int *Nf_out) {
+  NSK_CTX(ctx);
+  NSK_REQUIRE(Nf_out != nullptr && Nf >= 1 && cap >= Nf + 2, "regrid_front: bad arguments (Nf=%d cap=%d)", Nf, cap);
+  int *d_nf = reinterpret_cast<int *>(ctx->red_dev + 5);
+  *reinterpret_cast<int *>(ctx->red_host + 5) = Nf;
+  NSK_HIP(hipMemcpyAsync(d_nf, ctx->red_host + 5, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  k_regrid_front<<<1, 64, 0, ctx->stream>>>(xf, yf, xscratch, yscratch, dx, dy, d_nf, cap);
+  NSK_LAUNCH_CHECK();
+  NSK_HIP(hipMemcpyAsync(ctx->red_host + 5, d_nf, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  NSK_HIP(hipStreamSynchronize(ctx->stream));
+  *Nf_out = *reinterpret_cast<int *>(ctx->red_host + 5);
+  NSK_REQUIRE(*Nf_out >= 0, "regrid_front: the front outgrew its capacity of %d points", cap);
+  return 0;
+}

@@ -1,0 +1,122 @@
+"""ctypes wrapper of oracle/bubble_oracle.c -- TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .ns_oracle import build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_D, _I, _P = C.c_double, C.c_int, C.c_void_p
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and (a.flags.f_contiguous or a.ndim == 1), (a.dtype, a.shape)
+    return a.ctypes.data_as(_P)
+
+
+class C3State(C.Structure):
+    _fields_ = [(n, _P) for n in ("u", "v", "p", "ut", "vt", "tmp1", "tmp2", "fx", "fy", "un", "vn", "r", "m",
+                                  "rn", "mn", "rt", "xf", "yf", "xfn", "yfn", "uf", "vf", "tx", "ty")] + \
+               [("Nf", _I), ("cap", _I)]
+
+
+class C3Params(C.Structure):
+    _fields_ = [("nx", _I), ("ny", _I), ("maxit", _I)] + \
+               [(n, _D) for n in ("Lx", "Ly", "gx", "gy", "rho1", "rho2", "m1", "m2", "sigma", "rro", "usouth",
+                                  "unorth", "vwest", "veast", "dt", "dx", "dy", "maxError", "beta")]
+
+
+class BubbleOracle:
+    def __init__(self):
+        build()
+        self.lib = C.CDLL(os.path.join(_HERE, "libnsoracle.so"))
+        for n in ("bub_solve_pressure", "bub_construct_den", "bub_move_front", "bub_regrid_front",
+                  "bub_code1_step", "bub_code3_step"):
+            getattr(self.lib, n).restype = _I
+
+    def __getattr__(self, name):
+        fn = getattr(self.lib, "bub_" + name)
+
+        def call(*args):
+            conv = []
+            for a in args:
+                if isinstance(a, np.ndarray) or a is None:
+                    conv.append(_p(a))
+                elif isinstance(a, float):
+                    conv.append(_D(a))
+                else:
+                    conv.append(a)
+            return fn(*conv)
+        return call
+
+
+F = lambda *s, fill=0.0: np.full(s, fill, order="F")
+
+
+class OracleDNS:
+    """code1.m state stepped by the oracle (parameters = navierstokes_amd.bubble.DNSParams)."""
+
+    def __init__(self, q):
+        from navierstokes_amd.bubble import cell_centres
+        self.q, self.o = q, BubbleOracle()
+        nx, ny = q.nx, q.ny
+        self.rho, self.rhot, self.rho_o = F(nx + 2, ny + 2, fill=q.rho1), F(nx + 2, ny + 2), F(nx + 2, ny + 2)
+        self.u, self.v, self.p = F(nx + 1, ny + 2), F(nx + 2, ny + 1), F(nx + 2, ny + 2)
+        self.ut, self.vt = F(nx + 1, ny + 2), F(nx + 2, ny + 1)
+        self.uu, self.vv = F(nx + 1, ny + 1), F(nx + 1, ny + 1)
+        self.tmp1, self.tmp2 = F(nx + 2, ny + 2), F(nx + 2, ny + 2)
+        self.o.set_density(self.rho, None, q.xcenter, q.ycenter, cell_centres(nx, q.dx), cell_centres(ny, q.dy),
+                           q.rad, q.rho2, 0.0, nx, ny)
+
+    def step(self) -> int:
+        q = self.q
+        it = self.o.code1_step(self.u, self.v, self.p, self.rho, self.ut, self.vt, self.tmp1, self.tmp2, self.rhot,
+                               self.rho_o, q.dt, q.dx, q.dy, q.gx, q.gy, q.m0, q.usouth, q.unorth, q.vwest, q.veast,
+                               q.beta, q.maxit, q.maxerr, q.nx, q.ny)
+        self.o.velocity(self.uu, self.vv, self.u, self.v, q.nx, q.ny)
+        return it
+
+
+class OracleCode3:
+    """code3_fun.jl state stepped by the oracle (parameters = navierstokes_amd.bubble.Code3Params)."""
+
+    GRID = ("u", "v", "p", "ut", "vt", "tmp1", "tmp2", "fx", "fy", "un", "vn", "r", "m", "rn", "mn", "rt")
+    FRONT = ("xf", "yf", "xfn", "yfn", "uf", "vf", "tx", "ty")
+
+    def __init__(self, q):
+        from navierstokes_amd.bubble import front_circle
+        self.q, self.o = q, BubbleOracle()
+        nx, ny = q.nx, q.ny
+        shp = dict(u=(nx + 1, ny + 2), v=(nx + 2, ny + 1), ut=(nx + 1, ny + 2), vt=(nx + 2, ny + 1),
+                   un=(nx + 1, ny + 2), vn=(nx + 2, ny + 1))
+        for k in self.GRID:
+            setattr(self, k, F(*shp.get(k, (nx + 2, ny + 2))))
+        self.r[:] = q.rho1
+        self.m[:] = q.m1
+        for k in self.FRONT:
+            setattr(self, k, np.zeros(q.cap))
+        xf, yf = front_circle(q)
+        self.xf[: q.Nf + 2], self.yf[: q.Nf + 2] = xf, yf
+        self.Nf = q.Nf
+        self.sweeps = [0, 0, 0, 0]
+
+    def step(self):
+        q = self.q
+        st = C3State(**{k: getattr(self, k).ctypes.data for k in self.GRID + self.FRONT}, Nf=self.Nf, cap=q.cap)
+        pr = C3Params(nx=q.nx, ny=q.ny, maxit=q.maxit, Lx=q.Lx, Ly=q.Ly, gx=q.gx, gy=q.gy, rho1=q.rho1, rho2=q.rho2,
+                      m1=q.m1, m2=q.m2, sigma=q.sigma, rro=q.rro, usouth=q.usouth, unorth=q.unorth, vwest=q.vwest,
+                      veast=q.veast, dt=q.dt, dx=q.dx, dy=q.dy, maxError=q.maxError, beta=q.beta)
+        sw = (C.c_int * 4)()
+        rc = self.o.lib.bub_code3_step(C.byref(st), C.byref(pr), sw)
+        assert rc == 0, "front outgrew its capacity"
+        self.Nf = st.Nf
+        self.sweeps = list(sw)
+        return self.sweeps
+
+    def front(self):
+        return self.xf[: self.Nf + 2].copy(), self.yf[: self.Nf + 2].copy()

@@ -1,0 +1,187 @@
+"""DNS.jl (= code1.m) and code3_fun.jl kernels through the C ABI against the CPU oracle, bit for
+bit: every kernel on seeded random fields (ragged grids included), the single-workgroup
+anti-diagonal SOR against the lexicographic loop, the gather-form spreading against the
+sequential scatter, and whole time steps at the reference sizes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from navierstokes_amd.bubble import Code3, Code3Params, DNS, DNSParams, cell_centres, front_circle
+from oracle.bubble_oracle import BubbleOracle, OracleCode3, OracleDNS
+from util import Dev, same_bits
+
+pytestmark = pytest.mark.gpu
+GRIDS = [(2, 2), (5, 3), (32, 32), (70, 45), (129, 200)]
+
+
+@pytest.fixture(scope="module")
+def bo():
+    return BubbleOracle()
+
+
+def rf(rng, n1, n2, lo=None):
+    a = rng.standard_normal((n1, n2))
+    if lo is not None:
+        a = lo + rng.random((n1, n2))
+    return np.asfortranarray(a)
+
+
+def vec(a):
+    return Dev(np.asfortranarray(a.reshape(-1, 1)))
+
+
+@pytest.mark.parametrize("nx,ny", GRIDS)
+def test_grid_kernels(gpu, bo, nx, ny):
+    rng = np.random.default_rng(nx * 131 + ny)
+    dt, dx, dy = 0.00125, 1.0 / nx, 1.3 / ny
+    u, v = rf(rng, nx + 1, ny + 2), rf(rng, nx + 2, ny + 1)
+    r, m = rf(rng, nx + 2, ny + 2, 1.0), rf(rng, nx + 2, ny + 2, 0.01)
+    fx, fy, p = rf(rng, nx + 2, ny + 2), rf(rng, nx + 2, ny + 2), rf(rng, nx + 2, ny + 2)
+    ut, vt = rf(rng, nx + 1, ny + 2), rf(rng, nx + 2, ny + 1)
+    d = {k: Dev(a) for k, a in dict(u=u, v=v, r=r, m=m, fx=fx, fy=fy, p=p, ut=ut, vt=vt).items()}
+    # set_tangential
+    gpu.bub_set_tangential(d["u"].ptr, d["v"].ptr, 0.1, -0.1, 0.2, -0.2, nx, ny)
+    bo.set_tangential(u, v, 0.1, -0.1, 0.2, -0.2, nx, ny)
+    assert same_bits(d["u"].get(), u) and same_bits(d["v"].get(), v)
+    # code1 predictor
+    gpu.bub_temp_vel(d["ut"].ptr, d["vt"].ptr, d["u"].ptr, d["v"].ptr, d["r"].ptr, dt, dx, dy, 0.3, -100.0, 0.01, nx, ny)
+    bo.temp_uvel(ut, u, v, r, dt, dx, dy, 0.3, 0.01, nx, ny)
+    bo.temp_vvel(vt, u, v, r, dt, dx, dy, -100.0, 0.01, nx, ny)
+    assert same_bits(d["ut"].get(), ut) and same_bits(d["vt"].get(), vt)
+    # code3 predictor: advection then diffusion
+    gpu.bub_temp_vel_adv(d["ut"].ptr, d["vt"].ptr, d["u"].ptr, d["v"].ptr, d["r"].ptr, dt, dx, dy, d["fx"].ptr, d["fy"].ptr, 0.3, -100.0, 1.0, nx, ny)
+    bo.temp_uvel_adv(ut, u, v, r, dt, dx, dy, fx, 0.3, 1.0, nx, ny)
+    bo.temp_vvel_adv(vt, u, v, r, dt, dx, dy, fy, -100.0, 1.0, nx, ny)
+    assert same_bits(d["ut"].get(), ut) and same_bits(d["vt"].get(), vt)
+    gpu.bub_temp_vel_diff(d["ut"].ptr, d["vt"].ptr, d["u"].ptr, d["v"].ptr, d["r"].ptr, dt, dx, dy, d["m"].ptr, nx, ny)
+    bo.temp_uvel_diff(ut, u, v, r, dt, dx, dy, m, nx, ny)
+    bo.temp_vvel_diff(vt, u, v, r, dt, dx, dy, m, nx, ny)
+    assert same_bits(d["ut"].get(), ut) and same_bits(d["vt"].get(), vt)
+    # rt, sources
+    rt, t1, t2 = np.zeros_like(r), np.zeros_like(r), np.zeros_like(r)
+    drt, dt1, dt2 = Dev(rt), Dev(t1), Dev(t2)
+    gpu.bub_set_boundary(drt.ptr, d["r"].ptr, 1000.0, nx, ny)
+    bo.set_boundary(rt, r, 1000.0, nx, ny)
+    assert same_bits(drt.get(), rt)
+    gpu.bub_compute_sources(dt1.ptr, dt2.ptr, drt.ptr, d["ut"].ptr, d["vt"].ptr, dt, dx, dy, nx, ny)
+    bo.compute_sources(t1, t2, rt, ut, vt, dt, dx, dy, nx, ny)
+    assert same_bits(dt1.get(), t1) and same_bits(dt2.get(), t2)
+    # SOR: a few sweeps without convergence, then to convergence
+    for maxit, tol in ((3, 0.0), (200, 1e-3)):
+        sw, ch = C.c_int(0), C.c_double(0.0)
+        gpu.bub_solve_pressure(d["p"].ptr, dt1.ptr, dt2.ptr, drt.ptr, 1.2, dx, dy, nx, ny, maxit, tol, C.byref(sw), C.byref(ch))
+        chr_ = C.c_double(0.0)
+        it = bo.lib.bub_solve_pressure(p.ctypes.data_as(C.c_void_p), t1.ctypes.data_as(C.c_void_p), t2.ctypes.data_as(C.c_void_p),
+                                       rt.ctypes.data_as(C.c_void_p), C.c_double(1.2), C.c_double(dx), C.c_double(dy), nx, ny, maxit,
+                                       C.c_double(tol), C.byref(chr_))
+        assert sw.value == it and ch.value == chr_.value
+        assert same_bits(d["p"].get(), p)
+    # corrector, density advection, corner velocities, viscosity
+    gpu.bub_correct_vel(d["u"].ptr, d["v"].ptr, d["ut"].ptr, d["vt"].ptr, d["p"].ptr, d["r"].ptr, dt, dx, dy, nx, ny)
+    bo.correct_uvel(u, ut, p, r, dt, dx, nx, ny)
+    bo.correct_vvel(v, vt, p, r, dt, dy, nx, ny)
+    assert same_bits(d["u"].get(), u) and same_bits(d["v"].get(), v)
+    ro = r.copy(order="F")
+    dro = Dev(ro)
+    gpu.bub_advect_density(d["r"].ptr, dro.ptr, d["u"].ptr, d["v"].ptr, dt, dx, dy, 0.01, nx, ny)
+    bo.advect_density(r, ro, u, v, dt, dx, dy, 0.01, nx, ny)
+    assert same_bits(d["r"].get(), r)
+    uu, vv = np.zeros((nx + 1, ny + 1), order="F"), np.zeros((nx + 1, ny + 1), order="F")
+    duu, dvv = Dev(uu), Dev(vv)
+    gpu.bub_velocity(duu.ptr, dvv.ptr, d["u"].ptr, d["v"].ptr, nx, ny)
+    bo.velocity(uu, vv, u, v, nx, ny)
+    assert same_bits(duu.get(), uu) and same_bits(dvv.get(), vv)
+    gpu.bub_update_visco(d["r"].ptr, d["m"].ptr, 0.01, 0.05, 1.0, 2.0, nx, ny)
+    bo.update_visco(r, m, 0.01, 0.05, 1.0, 2.0, nx, ny)
+    assert same_bits(d["m"].get(), m)
+    # density SOR
+    sw = C.c_int(0)
+    gpu.bub_construct_den(d["r"].ptr, d["fx"].ptr, d["fy"].ptr, 1.2, 50, 1e-3, dx, dy, nx, ny, C.byref(sw))
+    it = bo.construct_den(r, fx, fy, 1.2, 50, 1e-3, dx, dy, nx, ny)
+    assert sw.value == it and same_bits(d["r"].get(), r)
+    gpu.bub_average(d["r"].ptr, dro.ptr, r.size)
+    assert same_bits(d["r"].get(), 0.5 * (r + ro))
+
+
+def test_set_density(gpu, bo):
+    nx, ny = 61, 40
+    x, y = cell_centres(nx, 1.0 / nx), cell_centres(ny, 1.0 / ny)
+    r, m = np.full((nx + 2, ny + 2), 1.0, order="F"), np.full((nx + 2, ny + 2), 0.01, order="F")
+    dr, dm, dx_, dy_ = Dev(r), Dev(m), vec(x), vec(y)     # keep every device array referenced
+    gpu.bub_set_density(dr.ptr, dm.ptr, 0.5, 0.7, dx_.ptr, dy_.ptr, 0.15, 2.0, 0.05, nx, ny)
+    bo.set_density(r, m, 0.5, 0.7, x, y, 0.15, 2.0, 0.05, nx, ny)
+    assert same_bits(dr.get(), r) and same_bits(dm.get(), m) and (r == 2.0).sum() > 10
+
+
+@pytest.mark.parametrize("nx,ny,Nf", [(32, 32, 100), (48, 20, 37), (16, 64, 400)])
+def test_front_kernels(gpu, bo, nx, ny, Nf):
+    q = Code3Params(nx=nx, ny=ny, Nf=Nf)
+    dx, dy = q.dx, q.dy
+    rng = np.random.default_rng(Nf)
+    xf, yf = front_circle(q)
+    xf[1:Nf + 1] += rng.standard_normal(Nf) * 0.004
+    yf[1:Nf + 1] += rng.standard_normal(Nf) * 0.004
+    xf[0], yf[0], xf[Nf + 1], yf[Nf + 1] = xf[Nf], yf[Nf], xf[1], yf[1]
+    cap = Nf * 3
+    pad = lambda a: np.concatenate([a, np.zeros(cap - a.size)])
+    dxf, dyf = vec(pad(xf)), vec(pad(yf))
+    tx, ty = np.zeros(cap), np.zeros(cap)
+    dtx, dty = vec(tx), vec(ty)
+    fx, fy = np.zeros((nx + 2, ny + 2), order="F"), np.zeros((nx + 2, ny + 2), order="F")
+    dfx, dfy = Dev(fx + 7.0), Dev(fy - 7.0)       # must be overwritten, not accumulated into
+    gpu.bub_surface_tension(dfx.ptr, dfy.ptr, dtx.ptr, dty.ptr, dxf.ptr, dyf.ptr, 10.0, dx, dy, nx, ny, Nf)
+    bo.front_tangents(tx, ty, xf, yf, Nf)
+    bo.surface_tension(fx, fy, xf, yf, tx, ty, 10.0, dx, dy, nx, ny, Nf)
+    assert same_bits(dtx.get()[: Nf + 2, 0], tx[: Nf + 2]) and same_bits(dty.get()[: Nf + 2, 0], ty[: Nf + 2])
+    assert same_bits(dfx.get(), fx) and same_bits(dfy.get(), fy) and np.abs(fx).max() > 0
+    gpu.bub_distribute(dfx.ptr, dfy.ptr, dxf.ptr, dyf.ptr, 1.0, 2.0, dx, dy, nx, ny, Nf)
+    bo.distribute(fx, fy, xf, yf, 1.0, 2.0, dx, dy, nx, ny, Nf)
+    assert same_bits(dfx.get(), fx) and same_bits(dfy.get(), fy)
+    # advect + move
+    u, v = rf(rng, nx + 1, ny + 2), rf(rng, nx + 2, ny + 1)
+    uf, vf = np.zeros(cap), np.zeros(cap)
+    duf, dvf = vec(uf), vec(vf)
+    cnt = C.c_int(-1)
+    du, dv = Dev(u), Dev(v)
+    gpu.bub_advect_move_front(duf.ptr, dvf.ptr, dxf.ptr, dyf.ptr, du.ptr, dv.ptr, dx, dy, 0.00125, 1.0, 1.0, nx, ny, Nf, C.byref(cnt))
+    bo.advect_front(uf, vf, xf, yf, u, v, dx, dy, nx, Nf)
+    out = bo.move_front(xf, yf, uf, vf, Nf, 0.00125, 1.0, 1.0)
+    assert cnt.value == out
+    assert same_bits(duf.get()[: Nf + 2, 0], uf[: Nf + 2]) and same_bits(dvf.get()[: Nf + 2, 0], vf[: Nf + 2])
+    assert same_bits(dxf.get()[: Nf + 2, 0], xf) and same_bits(dyf.get()[: Nf + 2, 0], yf)
+    # regrid: stretch one half of the front so that points are added and removed
+    xf[1:Nf // 2] = 0.5 + (xf[1:Nf // 2] - 0.5) * 1.6
+    xf[0], xf[Nf + 1] = xf[Nf], xf[1]
+    dxf, dyf = vec(pad(xf)), vec(pad(yf))
+    nf = C.c_int(0)
+    sx, sy = vec(np.zeros(cap)), vec(np.zeros(cap))
+    gpu.bub_regrid_front(dxf.ptr, dyf.ptr, sx.ptr, sy.ptr, dx, dy, Nf, cap, C.byref(nf))
+    xo, yo = pad(xf), pad(yf)
+    n2 = bo.regrid_front(xo, yo, dx, dy, Nf, cap)
+    assert nf.value == n2 and n2 != Nf
+    assert same_bits(dxf.get()[: n2 + 2, 0], xo[: n2 + 2]) and same_bits(dyf.get()[: n2 + 2, 0], yo[: n2 + 2])
+
+
+def test_dns_steps():
+    """scripts/DNS.jl at its sizes (32 x 32, dt .00125, beta 1.2, maxit 400): 25 steps."""
+    q = DNSParams()
+    g, o = DNS(q), OracleDNS(q)
+    for _ in range(25):
+        assert g.step() == o.step()
+    for k in ("rho", "u", "v", "p", "uu", "vv"):
+        assert same_bits(getattr(g, k).get(), getattr(o, k)), k
+
+
+def test_code3_steps():
+    """scripts/code3_fun.jl at its sizes (32 x 32, Nf = 100): 12 steps incl. front regridding."""
+    q = Code3Params()
+    g, o = Code3(q), OracleCode3(q)
+    for _ in range(12):
+        assert g.step() == o.step()
+        assert g.Nf == o.Nf
+    for k in ("r", "m", "u", "v", "p"):
+        assert same_bits(getattr(g, k).get(), getattr(o, k)), k
+    gx, gy = g.front()
+    ox, oy = o.front()
+    assert same_bits(gx, ox) and same_bits(gy, oy)
