@@ -88,6 +88,10 @@ int nsk_set_sphere(nsk_ctx *ctx, double *C, double *Vx, double *Vy, double a2,
 /* update_∇V!  NavierStokes.jl:129-132, call site :82 */
 int nsk_update_divV(nsk_ctx *ctx, double *divV, const double *Vx,
                     const double *Vy, double dx, double dy, int nx, int ny);
+/* update_∇V! writing a pitched divV (leading dimension ld >= nx), as the fused
+ * Poisson entry points accept it */
+int nsk_update_divV_ld(nsk_ctx *ctx, double *divV, int ld, const double *Vx,
+                       const double *Vy, double dx, double dy, int nx, int ny);
 /* update_dPrdτ! NavierStokes.jl:134-137, call site :85 */
 int nsk_update_dPrdtau(nsk_ctx *ctx, const double *Pr, double *dPrdtau,
                        const double *divV, double rho, double dt, double dtau,
@@ -109,6 +113,9 @@ int nsk_maxabs(nsk_ctx *ctx, const double *A, size_t count, double *out);
 /* correct_V!  NavierStokes.jl:149-153, call site :96 */
 int nsk_correct_V(nsk_ctx *ctx, double *Vx, double *Vy, const double *Pr,
                   double dt, double rho, double dx, double dy, int nx, int ny);
+/* correct_V! reading a pitched Pr (leading dimension ld >= nx) */
+int nsk_correct_V_ld(nsk_ctx *ctx, double *Vx, double *Vy, const double *Pr, int ld,
+                     double dt, double rho, double dx, double dy, int nx, int ny);
 /* set_bc_Vel! NavierStokes.jl:179-184 (bc_y!(Vx), bc_x!(Vy), bc_yV!(Vy,Vprof)),
  * call site :98 */
 int nsk_set_bc_Vel(nsk_ctx *ctx, double *Vx, double *Vy, const double *Vprof,

@@ -48,6 +48,8 @@ _SIGS = {
     "nsk_predict_V": [_P, _P, _P, _P, _P, _D, _D, _D, _D, _D, _I, _I],
     "nsk_set_sphere": [_P, _P, _P] + [_D] * 10 + [_I, _I, _I],
     "nsk_update_divV": [_P, _P, _P, _D, _D, _I, _I],
+    "nsk_update_divV_ld": [_P, _I, _P, _P, _D, _D, _I, _I],
+    "nsk_correct_V_ld": [_P, _P, _P, _I, _D, _D, _D, _D, _I, _I],
     "nsk_update_dPrdtau": [_P, _P, _P, _D, _D, _D, _D, _D, _D, _I, _I],
     "nsk_update_Pr": [_P, _P, _D, _I, _I],
     "nsk_set_bc_Pr": [_P, _D, _I, _I, _I, _I, _I],

@@ -308,7 +308,9 @@ extern "C" int nsk_set_sphere(nsk_ctx *ctx, double *C, double *Vx, double *Vy, d
   return 0;
 }
 
-// Pitched variant shared with the fused time step (ld = leading dimension of divV).
+// Pitched variant (ld = leading dimension of divV).
+extern "C" int nsk_update_divV_ld(nsk_ctx *ctx, double *divV, int ld, const double *Vx,
+                                  const double *Vy, double dx, double dy, int nx, int ny);
 int nsk_i_update_divV(nsk_ctx *ctx, double *divV, int ld, const double *Vx, const double *Vy,
                       double dx, double dy, int nx, int ny) {
   k_update_divV<<<grid2(nx, ny), block2(), 0, ctx->stream>>>(divV, ld, Vx, Vy, dx, dy, nx, ny);
@@ -389,7 +391,9 @@ extern "C" int nsk_maxabs(nsk_ctx *ctx, const double *A, size_t count, double *o
   return nsk_read_maxabs(ctx, out);
 }
 
-// Pitched variant shared with the fused time step (ld = leading dimension of Pr).
+// Pitched variant (ld = leading dimension of Pr).
+extern "C" int nsk_correct_V_ld(nsk_ctx *ctx, double *Vx, double *Vy, const double *Pr, int ld,
+                                double dt, double rho, double dx, double dy, int nx, int ny);
 int nsk_i_correct_V(nsk_ctx *ctx, double *Vx, double *Vy, const double *Pr, int ld, double dt,
                     double rho, double dx, double dy, int nx, int ny) {
   k_correct_V<<<grid2(nx - 1, ny - 1), block2(), 0, ctx->stream>>>(Vx, Vy, Pr, ld, dt / rho, dx, dy,
@@ -441,4 +445,20 @@ extern "C" int nsk_advect(nsk_ctx *ctx, double *Vx, const double *Vx_o, double *
                                                               dy, nx, ny, iy0, nyg);
   NSK_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int nsk_update_divV_ld(nsk_ctx *ctx, double *divV, int ld, const double *Vx,
+                                  const double *Vy, double dx, double dy, int nx, int ny) {
+  NSK_CTX(ctx);
+  NSK_GRID_OK(nx, ny);
+  NSK_REQUIRE(ld >= nx, "update_divV: ld=%d smaller than nx=%d", ld, nx);
+  return nsk_i_update_divV(ctx, divV, ld, Vx, Vy, dx, dy, nx, ny);
+}
+
+extern "C" int nsk_correct_V_ld(nsk_ctx *ctx, double *Vx, double *Vy, const double *Pr, int ld,
+                                double dt, double rho, double dx, double dy, int nx, int ny) {
+  NSK_CTX(ctx);
+  NSK_GRID_OK(nx, ny);
+  NSK_REQUIRE(ld >= nx, "correct_V: ld=%d smaller than nx=%d", ld, nx);
+  return nsk_i_correct_V(ctx, Vx, Vy, Pr, ld, dt, rho, dx, dy, nx, ny);
 }

@@ -71,28 +71,53 @@ def make_slab(rank: int, world: int, ny_loc: int, halo: int) -> Slab:
     return Slab(rank, world, ny_loc, halo if world > 1 else 0, ny_loc * world)
 
 
-def exchange_rows(fields, slab: Slab, nrows: Optional[int] = None) -> None:
-    """Refresh the halo rows of every field in `fields` (tensors shaped (ny_win, ld), row = iy)
-    from the neighbours' owned rows.  One batched isend/irecv per neighbour and field."""
+def exchange_rows(fields, slab: Slab, nrows: Optional[int] = None, faces: bool = False) -> None:
+    """Refresh the halo rows of every field in `fields` (tensors shaped (rows, ld), row = iy)
+    from the neighbours' owned rows.  One batched isend/irecv per neighbour and field.
+
+    Cell fields have ny_win rows.  Face fields (faces=True: Vy) have ny_win+1 rows; face f is
+    the lower face of cell row f, a rank owns the faces of its own cell rows (the top rank
+    also the last face), so the window of the lower neighbour ends one face later than its
+    cell halo: h+1 faces travel downwards, h upwards."""
     if slab.world == 1:
         return
     h = slab.halo if nrows is None else nrows
-    ops = []
+    up = h + 1 if faces else h            # rows that travel towards the lower neighbour
     lo, hi = slab.own_lo, slab.own_hi
+    # A gloo group with device tensors (several ranks sharing one GPU in tests) stages through
+    # host memory; RCCL sends the device rows directly.
+    stage = fields[0].is_cuda and dist.get_backend() == "gloo"
+    ops, landing = [], []
+
+    def send(t, a, b, peer):
+        ops.append(dist.P2POp(dist.isend, t[a:b].cpu() if stage else t[a:b], peer))
+
+    def recv(t, a, b, peer):
+        if stage:
+            buf = torch.empty_like(t[a:b], device="cpu")
+            landing.append((t, a, b, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, peer))
+        else:
+            ops.append(dist.P2POp(dist.irecv, t[a:b], peer))
+
     for t in fields:
-        if slab.rank > 0:                       # lower neighbour
-            ops.append(dist.P2POp(dist.isend, t[lo:lo + h], slab.rank - 1))
-            ops.append(dist.P2POp(dist.irecv, t[lo - h:lo], slab.rank - 1))
-        if slab.rank < slab.world - 1:          # upper neighbour
-            ops.append(dist.P2POp(dist.isend, t[hi - h:hi], slab.rank + 1))
-            ops.append(dist.P2POp(dist.irecv, t[hi:hi + h], slab.rank + 1))
+        if slab.rank > 0:                       # lower neighbour: send my first rows, get its last
+            send(t, lo, lo + up, slab.rank - 1)
+            recv(t, lo - h, lo, slab.rank - 1)
+        if slab.rank < slab.world - 1:          # upper neighbour: send my last rows, get its first
+            send(t, hi - h, hi, slab.rank + 1)
+            recv(t, hi, hi + up, slab.rank + 1)
     for r in dist.batch_isend_irecv(ops):
         r.wait()
+    for t, a, b, buf in landing:
+        t[a:b].copy_(buf)
 
 
 def allreduce_maxabs(value: float, device) -> float:
     """MAX all-reduce that keeps NaN: reduces the bit pattern of the non-negative double."""
     bits = struct.unpack("<q", struct.pack("<d", abs(value) if value == value else float("nan")))[0]
+    if dist.is_initialized() and dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([bits & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -151,6 +176,46 @@ class HipBackend:
         from .ns import c_params
         self.C, self.ctx, self.p, self.ld, self._c_params = C, ctx, p, ld, c_params
 
+    @staticmethod
+    def _P(t):
+        import ctypes as C
+        return C.c_void_p(t.data_ptr())
+
+    # whole-step kernels on windows (argument lists of include/nsk.h) ---------------------
+    def update_tau(self, txx, tyy, txy, Vx, Vy, s):
+        p, P = self.p, self._P
+        self.ctx.update_tau(P(txx), P(tyy), P(txy), P(Vx), P(Vy), p.mu, p.dx, p.dy, p.nx, s.ny_win)
+
+    def predict_V(self, Vx, Vy, txx, tyy, txy, s):
+        p, P = self.p, self._P
+        self.ctx.predict_V(P(Vx), P(Vy), P(txx), P(tyy), P(txy), p.rho, p.g, p.dt, p.dx, p.dy, p.nx, s.ny_win)
+
+    def set_sphere(self, Cc, Vx, Vy, s):
+        p, P = self.p, self._P
+        self.ctx.set_sphere(P(Cc), P(Vx), P(Vy), p.a2, p.b2, p.ox, p.oy, p.sinb, p.cosb, p.lx, p.ly, p.dx, p.dy,
+                            p.nx, s.ny_win, s.iy0)
+
+    def update_divV(self, divV, Vx, Vy, s):
+        p, P = self.p, self._P
+        self.ctx.update_divV_ld(P(divV), self.ld, P(Vx), P(Vy), p.dx, p.dy, p.nx, s.ny_win)
+
+    def correct_V(self, Vx, Vy, Pr, s):
+        p, P = self.p, self._P
+        self.ctx.correct_V_ld(P(Vx), P(Vy), P(Pr), self.ld, p.dt, p.rho, p.dx, p.dy, p.nx, s.ny_win)
+
+    def set_bc_Vel(self, Vx, Vy, Vprof, s):
+        p, P = self.p, self._P
+        self.ctx.set_bc_Vel(P(Vx), P(Vy), P(Vprof), p.nx, s.ny_win, int(p.full_rows), s.iy0, s.nyg)
+
+    def advect(self, Vx, Vx_o, Vy, Vy_o, Cc, C_o, s):
+        p, P = self.p, self._P
+        self.ctx.advect(P(Vx), P(Vx_o), P(Vy), P(Vy_o), P(Cc), P(C_o), p.dt, p.dx, p.dy, p.nx, s.ny_win, s.iy0, s.nyg)
+
+    def maxabs(self, t) -> float:
+        m = self.C.c_double(0.0)
+        self.ctx.maxabs(self._P(t), t.numel(), self.C.byref(m))
+        return m.value
+
     def _cp(self, slab: Slab):
         return self._c_params(self.p, ld_pr=self.ld, dp_embedded=1, iy0=slab.iy0, nyg=slab.nyg,
                               ny=slab.ny_win)
@@ -169,3 +234,68 @@ class HipBackend:
         self.ctx.ns_residual(None, C.c_void_p(Pr.data_ptr()), C.c_void_p(divV.data_ptr()), C.byref(cp),
                              slab.own_lo + 1, slab.own_hi, C.byref(m))
         return m.value
+
+
+class SlabNavierStokes:
+    """Whole time step of runme() (scripts/NavierStokes.jl:77-100) on one rank's slab.
+
+    Every field is a window of the global field covering the rank's rows plus `halo` rows per
+    interior side (Vy: one more face).  The kernels act on the whole window with their guards on
+    window extents; a kernel that needs a neighbour row leaves the outermost halo row stale, so
+    validity shrinks by one row per dependent kernel and is restored by two exchanges per step:
+    divV before the Poisson loop (which needs all `halo` rows) and Vx, Vy, C after advect!.
+    The back-trace of advect! reaches ceil(|V| dt / d)+1 rows; a device-side max|Vy| check
+    (all-reduced) guards that this stays inside the valid halo.
+
+    `backend` provides, on window tensors shaped (rows, ld):
+        update_tau, predict_V, set_sphere, update_divV, correct_V, set_bc_Vel, advect, maxabs
+        poisson_iters, residual_max                          (see SlabPoisson)
+    """
+
+    def __init__(self, p: NSParams, slab: Slab, backend, device, ld: int, vprof):
+        self.p, self.slab, self.be, self.dev, self.ld = p, slab, backend, device, ld
+        nx, nw = p.nx, slab.ny_win
+        z = lambda rows, cols: torch.zeros((rows, cols), dtype=torch.float64, device=device)
+        # NavierStokes.jl:58-70 on the window (Pr, dPrdtau, divV pitched; the rest dense)
+        self.Pr, self.dP, self.divV = z(nw, ld), z(nw, ld), z(nw, ld)
+        self.C, self.C_o = z(nw, nx), z(nw, nx)
+        self.txx, self.tyy, self.txy = z(nw, nx), z(nw, nx), z(nw - 1, nx - 1)
+        self.Vx, self.Vx_o = z(nw, nx + 1), z(nw, nx + 1)
+        self.Vy, self.Vy_o = z(nw + 1, nx), z(nw + 1, nx)
+        self.Vprof = torch.as_tensor(vprof, dtype=torch.float64).to(device)
+        if slab.iy0 == 0:
+            self.Vy[0, :] = self.Vprof          # NavierStokes.jl:73
+        self.poisson = SlabPoisson(p, slab, backend, self.Pr, self.dP, self.divV)
+        self.hist = []
+
+    def step(self) -> int:
+        p, s, be = self.p, self.slab, self.be
+        be.update_tau(self.txx, self.tyy, self.txy, self.Vx, self.Vy, s)
+        be.predict_V(self.Vx, self.Vy, self.txx, self.tyy, self.txy, s)
+        be.set_sphere(self.C, self.Vx, self.Vy, s)
+        be.update_divV(self.divV, self.Vx, self.Vy, s)
+        exchange_rows((self.divV,), s)
+        iters, self.hist = self.poisson.solve()
+        be.correct_V(self.Vx, self.Vy, self.Pr, s)
+        be.set_sphere(self.C, self.Vx, self.Vy, s)
+        be.set_bc_Vel(self.Vx, self.Vy, self.Vprof, s)
+        if s.world > 1:
+            # rows the back-trace may reach: |Vy| dt/dy + 1 below/above; one halo row is already
+            # stale (predict_V!/correct_V! do not update a window's outermost row)
+            reach = allreduce_maxabs(be.maxabs(self.Vy), self.dev) * p.dt / p.dy + 2
+            if not reach <= s.halo - 1:
+                raise RuntimeError(f"advect! reaches {reach:.1f} rows but only {s.halo - 1} valid halo rows "
+                                   f"exist: raise the halo width")
+        self.Vx_o.copy_(self.Vx)
+        self.Vy_o.copy_(self.Vy)
+        self.C_o.copy_(self.C)
+        be.advect(self.Vx, self.Vx_o, self.Vy, self.Vy_o, self.C, self.C_o, s)
+        exchange_rows((self.Vx, self.C), s)
+        exchange_rows((self.Vy,), s, faces=True)
+        return iters
+
+    def owned(self, name: str):
+        """Rows of a field this rank owns (cells; for Vy its faces, the top rank one more)."""
+        s, t = self.slab, getattr(self, name)
+        hi = s.own_hi + (1 if name in ("Vy", "Vy_o") and s.rank == s.world - 1 else 0)
+        return t[s.own_lo:hi]

@@ -45,6 +45,63 @@ class OracleWindowBackend:
         Pr[:, :nx] = torch.from_numpy(np.ascontiguousarray(a.T))
         dP[:, :nx] = torch.from_numpy(np.ascontiguousarray(d.T))
 
+    # ---- whole-step kernels on windows (used by SlabNavierStokes) -------------------------
+    def _run(self, tensors, widths, fn):
+        """copy windows to Fortran arrays, call fn(*arrays), copy back"""
+        arrs = [self._f(t, w) for t, w in zip(tensors, widths)]
+        fn(*arrs)
+        for t, w, a in zip(tensors, widths, arrs):
+            t[:, :w] = torch.from_numpy(np.ascontiguousarray(a.T))
+
+    def update_tau(self, txx, tyy, txy, Vx, Vy, s):
+        p, nx = self.p, self.p.nx
+        self._run((txx, tyy, txy, Vx, Vy), (nx, nx, nx - 1, nx + 1, nx),
+                  lambda a, b, c, d, e: self.o.update_tau(a, b, c, d, e, p.mu, p.dx, p.dy))
+
+    def predict_V(self, Vx, Vy, txx, tyy, txy, s):
+        p, nx = self.p, self.p.nx
+        self._run((Vx, Vy, txx, tyy, txy), (nx + 1, nx, nx, nx, nx - 1),
+                  lambda a, b, c, d, e: self.o.predict_V(a, b, c, d, e, p.rho, p.g, p.dt, p.dx, p.dy))
+
+    def set_sphere(self, Cc, Vx, Vy, s):
+        p, nx = self.p, self.p.nx
+        self._run((Cc, Vx, Vy), (nx, nx + 1, nx),
+                  lambda a, b, c: self.o.set_sphere(a, b, c, p.a2, p.b2, p.ox, p.oy, p.sinb, p.cosb, p.lx, p.ly,
+                                                    p.dx, p.dy, iy0=s.iy0))
+
+    def update_divV(self, divV, Vx, Vy, s):
+        p, nx = self.p, self.p.nx
+        self._run((divV, Vx, Vy), (nx, nx + 1, nx), lambda a, b, c: self.o.update_divV(a, b, c, p.dx, p.dy))
+
+    def correct_V(self, Vx, Vy, Pr, s):
+        p, nx = self.p, self.p.nx
+        self._run((Vx, Vy, Pr), (nx + 1, nx, nx), lambda a, b, c: self.o.correct_V(a, b, c, p.dt, p.rho, p.dx, p.dy))
+
+    def set_bc_Vel(self, Vx, Vy, Vprof, s):
+        """NavierStokes.jl:179-184 on a window: only the physical edges, bc_x! on global rows."""
+        p, nx = self.p, self.p.nx
+        bottom, top = s.iy0 == 0, s.iy0 + s.ny_win == s.nyg
+        if bottom:
+            Vx[0, :nx + 1] = Vx[1, :nx + 1]
+        if top:
+            Vx[-1, :nx + 1] = Vx[-2, :nx + 1]
+        lim = ((s.nyg + 1) if p.full_rows else min(nx, s.nyg + 1)) - s.iy0
+        lim = max(0, min(lim, s.ny_win + 1))
+        Vy[:lim, 0] = Vy[:lim, 1]
+        Vy[:lim, nx - 1] = Vy[:lim, nx - 2]
+        if bottom:
+            Vy[0, :nx] = Vprof
+        if top:
+            Vy[-1, :nx] = Vy[-2, :nx]
+
+    def advect(self, Vx, Vx_o, Vy, Vy_o, Cc, C_o, s):
+        p, nx = self.p, self.p.nx
+        self._run((Vx, Vx_o, Vy, Vy_o, Cc, C_o), (nx + 1, nx + 1, nx, nx, nx, nx),
+                  lambda a, b, c, d, e, f: self.o.advect(a, b, c, d, e, f, p.dt, p.dx, p.dy))
+
+    def maxabs(self, t):
+        return float(t.abs().max())
+
     def residual_max(self, Pr, divV, slab):
         p, nx = self.p, self.p.nx
         a, v = self._f(Pr, nx), self._f(divV, nx)
@@ -120,3 +177,41 @@ def test_slab_poisson_matches_single_domain(tmp_path, world, halo):
     gotdP = torch.cat([q["dP"] for q in parts]).numpy().T
     assert np.array_equal(gotPr, Pr)
     assert np.array_equal(gotdP[1:-1, 1:-1], dP)
+
+
+def _step_worker(rank, world, port, halo, nx, ny_loc, steps, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from navierstokes_amd.dist import SlabNavierStokes
+        from navierstokes_amd.ns import init_vprof
+        nyg = ny_loc * world
+        p = ns_params("NavierStokes", nx=nx, ny=nyg, niter=40, nchk=10)
+        slab = make_slab(rank, world, ny_loc, halo)
+        sim = SlabNavierStokes(p, slab, OracleWindowBackend(p), torch.device("cpu"), nx + 1, init_vprof(p))
+        iters = [sim.step() for _ in range(steps)]
+        res = {k: sim.owned(k)[:, : {"Vx": nx + 1}.get(k, nx)].clone() for k in ("Pr", "Vx", "Vy", "C", "dP")}
+        res["iters"], res["hist"] = iters, sim.hist
+        torch.save(res, os.path.join(out, f"s{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,halo", [(2, 6), (3, 5)])
+def test_slab_time_steps_match_single_domain(tmp_path, world, halo):
+    """Whole time steps (NavierStokes.jl:77-100) on slabs == the single-domain oracle."""
+    from oracle.ns_oracle import OracleSim
+    nx, ny_loc, steps = 13, 12, 3
+    mp.spawn(_step_worker, args=(world, _free_port(), halo, nx, ny_loc, steps, str(tmp_path)), nprocs=world, join=True)
+    p = ns_params("NavierStokes", nx=nx, ny=ny_loc * world, niter=40, nchk=10)
+    ref = OracleSim(p)
+    iters = [ref.step() for _ in range(steps)]
+    parts = [torch.load(os.path.join(tmp_path, f"s{r}.pt")) for r in range(world)]
+    for q in parts:
+        assert q["iters"] == iters
+        assert [h[1] for h in q["hist"]] == ref.err_evo
+    for k in ("Pr", "Vx", "Vy", "C"):
+        got = torch.cat([q[k] for q in parts]).numpy().T
+        assert np.array_equal(got, getattr(ref, k)), k
+    got = torch.cat([q["dP"] for q in parts]).numpy().T
+    assert np.array_equal(got[1:-1, 1:-1], ref.dPrdtau)

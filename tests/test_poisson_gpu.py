@@ -96,16 +96,17 @@ def test_poisson_loop_with_checks(gpu, oracle):
     assert same_bits(dPr.get(), Pr) and same_bits(dDp.get(), dP) and same_bits(dRp.get(), Rp)
 
 
-def test_poisson_slab_windows(gpu, oracle):
+@pytest.mark.parametrize("count", [1, 3, 4, 5, 12])
+def test_poisson_slab_windows(gpu, oracle, count):
     """A window of a taller global grid: its first/last rows are halo rows that must stay untouched,
     and after `count` passes all rows further than `count` from a halo edge equal the global result."""
-    nx, nyg, count = 70, 96, 4
+    nx, nyg = 70, 96
     p = ns_params("NavierStokes", nx=nx, ny=nyg)
     rng = np.random.default_rng(11)
     Pr0, dP0, dv = rng_field(rng, nx, nyg), rng_field(rng, nx - 2, nyg - 2), rng_field(rng, nx, nyg, 10.0)
     Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
     oracle_iters(oracle, p, Pr, dP, dv, count, 0)
-    for lo, hi in [(0, 40), (30, 75), (60, 96)]:   # global 0-based row ranges [lo, hi)
+    for lo, hi in [(0, 40), (30, 75), (18, 72), (60, 96), (48, 96)]:   # global 0-based row ranges [lo, hi)
         wPr = np.asfortranarray(Pr0[:, lo:hi])
         wdv = np.asfortranarray(dv[:, lo:hi])
         wdP = np.asfortranarray(dP0[:, lo:hi - 2])     # dP row j <-> Pr row j+1
