@@ -40,7 +40,7 @@ namespace {
 using namespace nsk_poisson;
 
 namespace nsk_poisson {
-#define NSK_DECL(K) extern template int launch_k<K>(nsk_ctx *, PoissonArgs &, bool, int, int);
+#define NSK_DECL(K) extern template int launch_k<K>(nsk_ctx *, PoissonArgs &, bool, int, int, int);
 NSK_DECL(1) NSK_DECL(2) NSK_DECL(3) NSK_DECL(4) NSK_DECL(5) NSK_DECL(6) NSK_DECL(7) NSK_DECL(8)
 #undef NSK_DECL
 }  // namespace nsk_poisson
@@ -48,15 +48,16 @@ NSK_DECL(1) NSK_DECL(2) NSK_DECL(3) NSK_DECL(4) NSK_DECL(5) NSK_DECL(6) NSK_DECL
 namespace {
 
 int launch_poisson(nsk_ctx *ctx, PoissonArgs &A, int K, bool aligned, int div, int rpc) {
+  const int ep = ctx->poisson_edge_percent;
   switch (K) {
-    case 1: return launch_k<1>(ctx, A, aligned, div, rpc);
-    case 2: return launch_k<2>(ctx, A, aligned, div, rpc);
-    case 3: return launch_k<3>(ctx, A, aligned, div, rpc);
-    case 4: return launch_k<4>(ctx, A, aligned, div, rpc);
-    case 5: return launch_k<5>(ctx, A, aligned, div, rpc);
-    case 6: return launch_k<6>(ctx, A, aligned, div, rpc);
-    case 7: return launch_k<7>(ctx, A, aligned, div, rpc);
-    case 8: return launch_k<8>(ctx, A, aligned, div, rpc);
+    case 1: return launch_k<1>(ctx, A, aligned, div, rpc, ep);
+    case 2: return launch_k<2>(ctx, A, aligned, div, rpc, ep);
+    case 3: return launch_k<3>(ctx, A, aligned, div, rpc, ep);
+    case 4: return launch_k<4>(ctx, A, aligned, div, rpc, ep);
+    case 5: return launch_k<5>(ctx, A, aligned, div, rpc, ep);
+    case 6: return launch_k<6>(ctx, A, aligned, div, rpc, ep);
+    case 7: return launch_k<7>(ctx, A, aligned, div, rpc, ep);
+    case 8: return launch_k<8>(ctx, A, aligned, div, rpc, ep);
   }
   nsk_set_error("poisson: unsupported passes per launch %d", K);
   return 2;

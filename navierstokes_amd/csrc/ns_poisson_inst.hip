@@ -3,5 +3,5 @@
 #include "ns_poisson_kernel.h"
 
 namespace nsk_poisson {
-template int launch_k<NSK_K>(nsk_ctx *, PoissonArgs &, bool, int, int);
+template int launch_k<NSK_K>(nsk_ctx *, PoissonArgs &, bool, int, int, int);
 }  // namespace nsk_poisson

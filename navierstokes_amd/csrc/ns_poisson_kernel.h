@@ -3,6 +3,16 @@
 #pragma once
 #include "nsk_internal.h"
 
+// Build-time shape of the staged input path: rows requested ahead of the row in use, and
+// wavefronts resident per SIMD (bounds the register budget: 512 / NSK_WAVES per lane).
+#ifndef NSK_PFD
+#define NSK_PFD 3
+#endif
+#ifndef NSK_WAVES
+#define NSK_WAVES 2
+#endif
+#define NSK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NSK_WAVES, NSK_WAVES)))
+
 namespace nsk_poisson {
 
 struct PoissonArgs {
@@ -13,7 +23,9 @@ struct PoissonArgs {
   double *dp_dst;
   int nx, ny, ld, ldd;
   int dp_embedded;
-  int nstrips, nchunks, rows_per_chunk;
+  int nstrips, nchunks, rows_per_chunk;   // interior strips: chunks and rows per chunk
+  int nchunks_edge, rows_per_chunk_edge;  // the first and the last strip do more work per row
+  int n_interior_tasks;
   int xbc_rows;            // rows r < xbc_rows (0-based) receive the x-Neumann condition
   int phys_bottom, phys_top;
   double dx, dy, rho_dt, keep, dtau, topval;
@@ -54,14 +66,14 @@ __device__ __forceinline__ unsigned unsafe_key(double x) {
 // lane 63 receive 0).  v_mov_b32 with the DPP controls wave_shr:1 / wave_shl:1.
 __device__ __forceinline__ double lane_prev(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double lane_next(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 
@@ -94,6 +106,29 @@ __device__ __forceinline__ void store_pair(double *__restrict__ p, size_t off, b
   }
 }
 
+// ---- LDS helpers for the staged (LDS-DMA) input path ---------------------------------------
+// The staging rings are written by global_load_lds (asynchronous, counted in vmcnt) and read by
+// ds_read_b128 issued from inline asm, with the s_waitcnt placed by hand: if the compiler saw
+// ordinary LDS reads of a ring that LDS-DMA writes it would insert s_waitcnt vmcnt(0) before
+// each of them, which would drain the whole prefetch queue every step.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_cvoid_t;
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v4i_t lds_read16_nowait(unsigned byte_addr) {
+  v4i_t v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Re-defines x behind the wait so that no use of it can be scheduled ahead of the wait.
+__device__ __forceinline__ void pin_after_wait(v4i_t &x) { asm volatile("" : "+v"(x)); }
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ double2 as_double2(v4i_t v) {
+  return make_double2(__hiloint2double(v.y, v.x), __hiloint2double(v.w, v.z));
+}
+
 // One (strip, chunk) task, executed by one wavefront.
 //
 // Register state per pass s = 1..K (v = the lane's two adjacent cells), for the row r the
@@ -103,22 +138,38 @@ __device__ __forceinline__ void store_pair(double *__restrict__ p, size_t off, b
 //   E[s][v]        P_{s-1}[r] - P_{s-1}[r-1]: the lower half of the y second difference, which
 //                  is the upper half of the previous step's -- row r-1 itself is not kept
 //   D[s][ph][v]    pass s-1 dPrdτ of row r, D[s][ph^1][v] of row r+1
-// ρ/dt*∇V of the last K+1 rows sits in an LDS ring private to the wavefront.
+//
+// Input rows reach the wave in one of two ways:
+//   DMA (the vectorised storage): global_load_lds_dwordx4 streams the rows of Pr, dPrdτ and ∇V
+//       PFD rows ahead of their use into per-wave LDS rings, costing no registers while in
+//       flight; ∇V rows stay in their ring for K more steps, where the K passes read them.
+//   registers (any other storage): 8-byte loads one row ahead into registers, ρ/dt*∇V of the
+//       last K+1 rows in a small LDS ring.
 #ifndef NSK_PREFETCH_ROWS
 #define NSK_PREFETCH_ROWS 1
 #endif
+
+template <int K>
+struct DmaGeometry {
+  static constexpr int PFD = NSK_PFD;                 // rows requested ahead of the row in use
+  static constexpr int NST = PFD + 1;             // ring slots of Pr and of dPrdτ
+  static constexpr int NSG = PFD + K + 1;         // ring slots of ∇V (rows j-K .. j+PFD)
+  static constexpr int LDS_BYTES = (2 * NST + NSG) * 1024;
+};
 
 template <int K, bool ALIGNED, int DIV, bool EDGE>
 struct Task {
   static constexpr int HK = (K + 1) & ~1;    // column halo, even so that pairs stay aligned
   static constexpr int WOUT = 128 - 2 * HK;  // columns a strip produces
+  static constexpr bool DMA = ALIGNED;
   static constexpr int RING = K + 1;
-  static constexpr int PF = NSK_PREFETCH_ROWS;  // rows requested from memory ahead of use
+  static constexpr int PF = NSK_PREFETCH_ROWS;  // register path: rows requested ahead of use
   static constexpr int NSLOT = PF + 1;
-  static constexpr int UNROLL = NSLOT % 2 == 0 ? NSLOT : 2 * NSLOT;  // lcm(2, NSLOT)
+  static constexpr int UNROLL = DMA ? 2 : (NSLOT % 2 == 0 ? NSLOT : 2 * NSLOT);  // lcm(2, NSLOT)
+  static constexpr int PFD = DmaGeometry<K>::PFD, NST = DmaGeometry<K>::NST, NSG = DmaGeometry<K>::NSG;
 
   const PoissonArgs &A;
-  double2 *gring;  // [RING][64]
+  double2 *lds;  // register path: ∇V ring [RING][64]; DMA path: the three staging rings
   int lane, c0, r0, r1, jstart, jend;
   bool indom[2], inter[2], outcol[2];
   const double *__restrict__ prs;
@@ -127,16 +178,18 @@ struct Task {
   double *__restrict__ dpd;
   double *__restrict__ prd;
   size_t ld, ldd;
+  size_t cc;          // DMA path: this lane's column, clamped into the row
+  unsigned lds_lane;  // DMA path: LDS byte address of this lane's 16 bytes in slot 0
 
   double P[K + 1][2][2], E[K + 1][2], D[K + 1][2][2];
-  double LP[NSLOT][2], LD[NSLOT][2], LG[NSLOT][2];  // rows in flight from memory
+  double LP[NSLOT][2], LD[NSLOT][2], LG[NSLOT][2];  // register path: rows in flight
 
-  __device__ __forceinline__ Task(const PoissonArgs &a, double2 *ring, int sx, int cy)
-      : A(a), gring(ring) {
+  __device__ __forceinline__ Task(const PoissonArgs &a, double2 *shared, int sx, int row0, int row1)
+      : A(a), lds(shared) {
     lane = threadIdx.x & 63;
     c0 = sx * WOUT - HK + 2 * lane;
-    r0 = cy * A.rows_per_chunk;
-    r1 = min(r0 + A.rows_per_chunk, A.ny);
+    r0 = row0;
+    r1 = row1;
     jstart = max(r0 - K, 0);
     jend = min(r1 - 1 + K, A.ny - 1);
 #pragma unroll
@@ -156,6 +209,10 @@ struct Task {
     dps = A.dp_embedded ? A.dp_src : A.dp_src - ldd - 1;  // addressed by Pr cell coordinates
     dpd = A.dp_embedded ? A.dp_dst : A.dp_dst - ldd - 1;
     prd = A.pr_dst;
+    // Lanes outside the domain fetch some pair inside the row: their values are never used
+    // (such cells are carried through and not stored), the clamp only keeps the access legal.
+    cc = (size_t)min(max(c0, 0), A.ld - 2);
+    lds_lane = (unsigned)(uintptr_t)(lds_void_t *)shared + 16u * (unsigned)lane;
 #pragma unroll
     for (int s = 0; s <= K; s++)
 #pragma unroll
@@ -166,17 +223,57 @@ struct Task {
       }
   }
 
+  // ---- register path ---------------------------------------------------------------------
   __device__ __forceinline__ void load_row(int j, int slot) {
     const bool rowint = j >= 1 && j <= A.ny - 2;
     load_pair<ALIGNED>(prs, (size_t)j * ld + c0, indom[0], indom[1], LP[slot][0], LP[slot][1]);
-    if (ALIGNED && A.dp_embedded)
-      load_pair<true>(dps, (size_t)j * ldd + c0, rowint && inter[0], rowint && inter[1],
-                      LD[slot][0], LD[slot][1]);
-    else
-      load_pair<false>(dps, (size_t)j * ldd + c0, rowint && inter[0], rowint && inter[1],
-                       LD[slot][0], LD[slot][1]);
+    load_pair<false>(dps, (size_t)j * ldd + c0, rowint && inter[0], rowint && inter[1], LD[slot][0],
+                     LD[slot][1]);
     load_pair<ALIGNED>(dvs, (size_t)j * ld + c0, rowint && indom[0], rowint && indom[1],
                        LG[slot][0], LG[slot][1]);
+  }
+
+  // ---- DMA path ----------------------------------------------------------------------------
+  // Request row j: 1 KiB of each field straight into LDS, slot sp of the Pr and dPrdτ rings and
+  // slot sg of the ∇V ring (64 lanes x 16 bytes, lane-major).
+  __device__ __forceinline__ void dma_row(int j, int sp, int sg) {
+    const size_t off = (size_t)j * ld + cc;
+    char *base = reinterpret_cast<char *>(lds);
+    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(prs + off), (lds_void_t *)(base + sp * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(dps + off), (lds_void_t *)(base + (NST + sp) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(dvs + off), (lds_void_t *)(base + (2 * NST + sg) * 1024), 16, 0, 0);
+  }
+
+  // Row j of Pr and dPrdτ (slot sp) and ρ/dt*∇V of rows j-1 .. j-K (slots behind sg).
+  __device__ __forceinline__ void dma_fetch(int sp, int sg, bool want_row, double inP[2], double inD[2],
+                                            double2 g[K + 1]) {
+    v4i_t vp = {0, 0, 0, 0}, vd = {0, 0, 0, 0}, vg[K + 1];
+    if (want_row) {
+      vp = lds_read16_nowait(lds_lane + (unsigned)sp * 1024u);
+      vd = lds_read16_nowait(lds_lane + (unsigned)(NST + sp) * 1024u);
+    }
+#pragma unroll
+    for (int s = 1; s <= K; s++) {
+      int q = sg - s;
+      if (q < 0) q += NSG;
+      vg[s] = lds_read16_nowait(lds_lane + (unsigned)(2 * NST + q) * 1024u);
+    }
+    lds_wait_all();
+    pin_after_wait(vp);
+    pin_after_wait(vd);
+#pragma unroll
+    for (int s = 1; s <= K; s++) pin_after_wait(vg[s]);
+    const double2 p = as_double2(vp), d = as_double2(vd);
+    inP[0] = p.x;
+    inP[1] = p.y;
+    inD[0] = d.x;
+    inD[1] = d.y;
+#pragma unroll
+    for (int s = 1; s <= K; s++) {
+      // ρ/dt*∇V (NavierStokes.jl:135): the same product in every pass
+      const double2 r = as_double2(vg[s]);
+      g[s] = make_double2(A.rho_dt * r.x, A.rho_dt * r.y);
+    }
   }
 
   // One pass of one row: NavierStokes.jl:135 then :140, association as written there:
@@ -196,30 +293,51 @@ struct Task {
     }
   }
 
-  // One step: row j arrives, pass s advances to row j-s.  STEADY promises that every pass
-  // works on a row strictly inside the task's row range, away from the y boundaries, that
-  // row j+1 exists and that row j-K is one of the task's output rows; all row tests then
-  // vanish and the K passes form one straight-line block the scheduler can interleave.
-  template <int PH, int SL, bool STEADY>
-  __device__ __forceinline__ void step(int j, int ring_j) {
-    // row j is row r+1 of pass 1's window (r = j-1)
-    if (STEADY || j <= jend) {
+  // Columns 0 and nx-1 are not updated by the iteration itself.  In rows that bc_x! reaches
+  // they take the new value of their interior neighbour (Pr[1,iy]=Pr[2,iy];
+  // Pr[end,iy]=Pr[end-1,iy]); in the other rows they keep their value.  Cells outside the
+  // domain hold don't-care values: nothing reads them and they are never stored.
+  __device__ __forceinline__ void edge_fixups(int r, const double cen[2], const double dq[2],
+                                              double pnew[2], double dnew[2]) const {
+    if (r < A.xbc_rows) {
+      const double pl = lane_prev(pnew[1]);
+      if (c0 == 0) pnew[0] = pnew[1];
+      if (c0 + 1 == A.nx - 1) pnew[1] = pnew[0];
+      if (c0 == A.nx - 1) pnew[0] = pl;
+    } else {
+      if (c0 == 0 || c0 == A.nx - 1) pnew[0] = cen[0];
+      if (c0 + 1 == A.nx - 1) pnew[1] = cen[1];
+    }
+  }
+
+  __device__ __forceinline__ void store_dp(int r, const double dnew[2]) {
+    if (ALIGNED)
+      store_pair<true>(dpd, (size_t)r * ldd + c0, outcol[0] && inter[0], outcol[1] && inter[1],
+                       dnew[0], dnew[1]);
+    else
+      store_pair<false>(dpd, (size_t)r * ldd + c0, outcol[0] && inter[0], outcol[1] && inter[1],
+                        dnew[0], dnew[1]);
+  }
+
+  // General step: row j (inP, inD; ignored when j > jend) arrives, pass s advances to row j-s
+  // if that row is inside the task's range; every row test is evaluated.
+  template <int PH>
+  __device__ __forceinline__ void general_step(int j, const double inP[2], const double inD[2],
+                                               const double2 g[K + 1]) {
+    if (j <= jend) {
 #pragma unroll
       for (int v = 0; v < 2; v++) {
-        P[1][PH ^ 1][v] = LP[SL][v];
-        D[1][PH ^ 1][v] = LD[SL][v];
+        P[1][PH ^ 1][v] = inP[v];
+        D[1][PH ^ 1][v] = inD[v];
       }
-      // ρ/dt*∇V (NavierStokes.jl:135) is the same number in every pass: form it once
-      gring[ring_j * 64 + lane] = make_double2(A.rho_dt * LG[SL][0], A.rho_dt * LG[SL][1]);
     }
-    if (STEADY || j + PF <= jend) load_row(j + PF, (SL + PF) % NSLOT);
 #pragma unroll
     for (int s = 1; s <= K; s++) {
       const int r = j - s;  // row this pass works on now
-      if (STEADY || (r >= jstart && r <= jend)) {
+      if (r >= jstart && r <= jend) {
         double pnew[2], dnew[2];
         const double *cen = P[s][PH], *up = P[s][PH ^ 1], *dq = D[s][PH];
-        if (!STEADY && (r == jstart || r == jend)) {
+        if (r == jstart || r == jend) {
           // Edge row of the task: carried through unchanged.  It is either a halo row
           // (recomputed by the neighbouring task) or a boundary row of the window.
 #pragma unroll
@@ -229,9 +347,6 @@ struct Task {
             E[s][v] = up[v] - cen[v];
           }
         } else {
-          int rs = ring_j - s;
-          if (rs < 0) rs += RING;
-          const double2 g = gring[rs * 64 + lane];
           const double lft = lane_prev(cen[1]);  // left neighbour of cell 0
           const double rgt = lane_next(cen[0]);  // right neighbour of cell 1
           // x: (r-c)-(c-l); the middle difference serves both cells of the pair
@@ -242,7 +357,7 @@ struct Task {
           double low[2] = {E[s][0], E[s][1]};
           E[s][0] = upd[0];
           E[s][1] = upd[1];
-          if (!STEADY && s >= 2) {
+          if (s >= 2) {
             // Inputs are pass >= 1 values: rows 0 / ny-1 of that pass hold the y boundary
             // conditions (bc_yval!), which the carried-through edge rows do not.
             if (A.phys_bottom && r == 1) low[0] = low[1] = 0.0;  // Pr[ix,1] = Pr[ix,2]: c - d = +0
@@ -253,7 +368,7 @@ struct Task {
           }
           const double d2y[2] = {upd[0] - low[0], upd[1] - low[1]};
           if (DIV == DIV_IEEE) {
-            update_pair<DIV_IEEE>(d2x, d2y, dq, g, cen, pnew, dnew);
+            update_pair<DIV_IEEE>(d2x, d2y, dq, g[s], cen, pnew, dnew);
           } else {
             unsigned k0 = max(unsafe_key(d2x[0]), unsafe_key(d2y[0]));
             unsigned k1 = max(unsafe_key(d2x[1]), unsafe_key(d2y[1]));
@@ -262,25 +377,11 @@ struct Task {
               k1 = inter[1] ? k1 : 0u;
             }
             if (__builtin_amdgcn_ballot_w64(max(k0, k1) >= SAFE_SPAN) == 0)
-              update_pair<DIV>(d2x, d2y, dq, g, cen, pnew, dnew);
+              update_pair<DIV>(d2x, d2y, dq, g[s], cen, pnew, dnew);
             else
-              update_pair<DIV_IEEE>(d2x, d2y, dq, g, cen, pnew, dnew);
+              update_pair<DIV_IEEE>(d2x, d2y, dq, g[s], cen, pnew, dnew);
           }
-          if (EDGE) {
-#pragma unroll
-            for (int v = 0; v < 2; v++) {
-              if (!inter[v]) {  // boundary column or outside the domain: not updated
-                pnew[v] = cen[v];
-                dnew[v] = dq[v];
-              }
-            }
-            if (r < A.xbc_rows) {  // bc_x!: Pr[1,iy]=Pr[2,iy]; Pr[end,iy]=Pr[end-1,iy]
-              const double pl = lane_prev(pnew[1]);
-              if (c0 == 0) pnew[0] = pnew[1];
-              if (c0 + 1 == A.nx - 1) pnew[1] = pnew[0];
-              if (c0 == A.nx - 1) pnew[0] = pl;
-            }
-          }
+          if (EDGE) edge_fixups(r, cen, dq, pnew, dnew);
         }
         if (s < K) {
 #pragma unroll
@@ -288,14 +389,6 @@ struct Task {
             P[s + 1][PH ^ 1][v] = pnew[v];
             D[s + 1][PH ^ 1][v] = dnew[v];
           }
-        } else if (STEADY) {
-          store_pair<ALIGNED>(prd, (size_t)r * ld + c0, outcol[0], outcol[1], pnew[0], pnew[1]);
-          if (ALIGNED && A.dp_embedded)
-            store_pair<true>(dpd, (size_t)r * ldd + c0, outcol[0] && inter[0],
-                             outcol[1] && inter[1], dnew[0], dnew[1]);
-          else
-            store_pair<false>(dpd, (size_t)r * ldd + c0, outcol[0] && inter[0],
-                              outcol[1] && inter[1], dnew[0], dnew[1]);
         } else if (r >= r0 && r < r1) {
           const bool rowint = r >= 1 && r <= A.ny - 2;
           const bool first = r == 0, last = r == A.ny - 1;
@@ -306,85 +399,246 @@ struct Task {
           }
           if (r == 1 && A.phys_bottom)  // bc_yval!: Pr[ix,1] = Pr[ix,2]
             store_pair<ALIGNED>(prd, (size_t)c0, outcol[0], outcol[1], pnew[0], pnew[1]);
-          if (rowint) {
-            if (ALIGNED && A.dp_embedded)
-              store_pair<true>(dpd, (size_t)r * ldd + c0, outcol[0] && inter[0],
-                               outcol[1] && inter[1], dnew[0], dnew[1]);
-            else
-              store_pair<false>(dpd, (size_t)r * ldd + c0, outcol[0] && inter[0],
-                                outcol[1] && inter[1], dnew[0], dnew[1]);
-          }
+          if (rowint) store_dp(r, dnew);
         }
       }
     }
   }
 
-  __device__ __forceinline__ bool steady(int j) const {
-    // passes 1..K work on rows j-1 .. j-K
-    return j - K > jstart && j + PF <= jend && j - K >= r0 &&
-           (!A.phys_bottom || j - K >= 2) && (!A.phys_top || j <= A.ny - 2);
+  // All K passes of one steady step with one form of division and no commit: pass s reads
+  // P[s][PH] (row r), E[s], D[s][PH] and, as the row above, pass s-1's result of this same
+  // step (pn[s-1]; the newly arrived row for s = 1).  Returns the largest unsafe_key of the
+  // operands the FMA division saw.  Nothing of the task's state is written, so the caller
+  // can evaluate the step again with IEEE division when that key is out of range.
+  template <int QD, int PH>
+  __device__ __forceinline__ unsigned steady_levels(int j, const double2 g[K + 1], double pn[K + 1][2],
+                                                    double dn[K + 1][2], double ne[K + 1][2]) const {
+    unsigned key = 0;
+#pragma unroll
+    for (int s = 1; s <= K; s++) {
+      const int r = j - s;
+      const double *cen = P[s][PH], *dq = D[s][PH];
+      const double *up = s == 1 ? P[1][PH ^ 1] : pn[s - 1];
+      const double lft = lane_prev(cen[1]), rgt = lane_next(cen[0]);
+      const double tl = cen[0] - lft, tm = cen[1] - cen[0], tr = rgt - cen[1];
+      const double d2x[2] = {tm - tl, tr - tm};
+      ne[s][0] = up[0] - cen[0];
+      ne[s][1] = up[1] - cen[1];
+      const double d2y[2] = {ne[s][0] - E[s][0], ne[s][1] - E[s][1]};
+      if (QD != DIV_IEEE) {
+        unsigned k0 = max(unsafe_key(d2x[0]), unsafe_key(d2y[0]));
+        unsigned k1 = max(unsafe_key(d2x[1]), unsafe_key(d2y[1]));
+        if (EDGE) {
+          k0 = inter[0] ? k0 : 0u;
+          k1 = inter[1] ? k1 : 0u;
+        }
+        key = max(key, max(k0, k1));
+      }
+      update_pair<QD>(d2x, d2y, dq, g[s], cen, pn[s], dn[s]);
+      if (EDGE) edge_fixups(r, cen, dq, pn[s], dn[s]);
+    }
+    return key;
   }
 
-  template <int I, bool STEADY>
-  __device__ __forceinline__ void steps(int j, int &ring_j, int jlast) {
-    if constexpr (I < UNROLL) {
-      if (STEADY || j + I <= jlast) step<I % 2, I % NSLOT, STEADY>(j + I, ring_j);
-      ring_j = ring_j + 1 == RING ? 0 : ring_j + 1;
-      steps<I + 1, STEADY>(j, ring_j, jlast);
+  // Steady step: every pass works on a row strictly inside the task's row range, away from the
+  // y boundaries, and row j-K is one of the task's output rows, so no row test is needed; one
+  // safety test covers the whole step, which keeps the K passes in one basic block so that
+  // their independent parts overlap.
+  template <int PH>
+  __device__ __forceinline__ void steady_step(int j, const double inP[2], const double inD[2],
+                                              const double2 g[K + 1]) {
+#pragma unroll
+    for (int v = 0; v < 2; v++) {
+      P[1][PH ^ 1][v] = inP[v];
+      D[1][PH ^ 1][v] = inD[v];
+    }
+    double pn[K + 1][2], dn[K + 1][2], ne[K + 1][2];
+    const unsigned key = steady_levels<DIV, PH>(j, g, pn, dn, ne);
+    if (DIV != DIV_IEEE && __builtin_amdgcn_ballot_w64(key >= SAFE_SPAN) != 0)
+      steady_levels<DIV_IEEE, PH>(j, g, pn, dn, ne);
+#pragma unroll
+    for (int s = 1; s <= K; s++)
+#pragma unroll
+      for (int v = 0; v < 2; v++) {
+        E[s][v] = ne[s][v];
+        if (s < K) {
+          P[s + 1][PH ^ 1][v] = pn[s][v];
+          D[s + 1][PH ^ 1][v] = dn[s][v];
+        }
+      }
+    const int r = j - K;
+    if (!DMA || r >= r0) {  // (the register path enters steady steps only once r >= r0)
+      store_pair<ALIGNED>(prd, (size_t)r * ld + c0, outcol[0], outcol[1], pn[K][0], pn[K][1]);
+      store_dp(r, dn[K]);
     }
   }
 
-  __device__ __forceinline__ void run() {
+  __device__ __forceinline__ bool steady(int j) const {
+    // passes 1..K work on rows j-1 .. j-K; the row requested ahead must exist
+    return j - K > jstart && j + (DMA ? 0 : PF) <= jend && (DMA || j - K >= r0) &&
+           (!A.phys_bottom || j - K >= 2) && (!A.phys_top || j <= A.ny - 2);
+  }
+
+  // ---- register-path driver ----------------------------------------------------------------
+  template <int I, bool STEADY>
+  __device__ __forceinline__ void reg_steps(int j, int &ring_j, int jlast) {
+    if constexpr (I < UNROLL) {
+      constexpr int PH = I % 2, SL = I % NSLOT;
+      const int jj = j + I;
+      if (STEADY || jj <= jlast) {
+        if (STEADY || jj <= jend)
+          lds[ring_j * 64 + lane] = make_double2(A.rho_dt * LG[SL][0], A.rho_dt * LG[SL][1]);
+        double2 g[K + 1];
 #pragma unroll
-    for (int i = 0; i < PF; i++)
-      if (jstart + i <= jend) load_row(jstart + i, i);
-    int ring_j = 0;
+        for (int s = 1; s <= K; s++) {
+          int rs = ring_j - s;
+          if (rs < 0) rs += RING;
+          g[s] = lds[rs * 64 + lane];
+        }
+        const double inP[2] = {LP[SL][0], LP[SL][1]}, inD[2] = {LD[SL][0], LD[SL][1]};
+        if (STEADY || jj + PF <= jend) load_row(jj + PF, (SL + PF) % NSLOT);
+        if constexpr (STEADY)
+          steady_step<PH>(jj, inP, inD, g);
+        else
+          general_step<PH>(jj, inP, inD, g);
+      }
+      ring_j = ring_j + 1 == RING ? 0 : ring_j + 1;
+      reg_steps<I + 1, STEADY>(j, ring_j, jlast);
+    }
+  }
+
+  // ---- DMA-path driver -----------------------------------------------------------------------
+  template <int PH, bool STEADY>
+  __device__ __forceinline__ void dma_step(int j, int &sp, int &sg, bool &drained) {
+    // Row j was requested PFD steps ago.  vmcnt counts row requests and stores together in
+    // issue order; while rows are still being requested, the PFD-1 steps since have each put
+    // 3 younger requests behind row j's (their stores only add to that), so waiting for all
+    // but 3*(PFD-1) operations guarantees that row j has landed while about half of the
+    // requested rows stay in flight.  Once the last row has been requested one full drain
+    // covers every remaining step.
+    if (j + PFD - 1 <= jend) {
+      vm_wait<3 * (PFD - 1)>();
+    } else if (!drained) {
+      vm_wait<0>();
+      drained = true;
+    }
+    double inP[2], inD[2];
+    double2 g[K + 1];
+    dma_fetch(sp, sg, STEADY || j <= jend, inP, inD, g);
+    if (j + PFD <= jend) {
+      int np = sp + PFD, ng = sg + PFD;
+      if (np >= NST) np -= NST;
+      if (ng >= NSG) ng -= NSG;
+      dma_row(j + PFD, np, ng);
+    }
+    if constexpr (STEADY)
+      steady_step<PH>(j, inP, inD, g);
+    else
+      general_step<PH>(j, inP, inD, g);
+    sp = sp + 1 == NST ? 0 : sp + 1;
+    sg = sg + 1 == NSG ? 0 : sg + 1;
+  }
+
+  __device__ __forceinline__ void run() {
     const int jlast = jend + K;
-    for (int j = jstart; j <= jlast; j += UNROLL) {
-      if (steady(j) && steady(j + UNROLL - 1))
-        steps<0, true>(j, ring_j, jlast);
-      else
-        steps<0, false>(j, ring_j, jlast);
+    if constexpr (DMA) {
+#pragma unroll
+      for (int i = 0; i < PFD; i++)
+        if (jstart + i <= jend) dma_row(jstart + i, i % NST, i % NSG);
+      int sp = 0, sg = 0;
+      bool drained = false;
+      for (int j = jstart; j <= jlast; j += 2) {
+        if (steady(j) && steady(j + 1)) {
+          dma_step<0, true>(j, sp, sg, drained);
+          dma_step<1, true>(j + 1, sp, sg, drained);
+        } else {
+          dma_step<0, false>(j, sp, sg, drained);
+          if (j + 1 <= jlast) dma_step<1, false>(j + 1, sp, sg, drained);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PF; i++)
+        if (jstart + i <= jend) load_row(jstart + i, i);
+      int ring_j = 0;
+      for (int j = jstart; j <= jlast; j += UNROLL) {
+        if (steady(j) && steady(j + UNROLL - 1))
+          reg_steps<0, true>(j, ring_j, jlast);
+        else
+          reg_steps<0, false>(j, ring_j, jlast);
+      }
     }
   }
 };
 
 template <int K, bool ALIGNED, int DIV>
-__global__ void __launch_bounds__(64) k_poisson(PoissonArgs A) {
-  __shared__ double2 gring[(K + 1) * 64];
-  const int task = blockIdx.x;
-  const int sx = task % A.nstrips, cy = task / A.nstrips;
+__global__ void __launch_bounds__(64) NSK_WAVES_ATTR k_poisson(PoissonArgs A) {
+  constexpr int LDS_VEC = ALIGNED ? DmaGeometry<K>::LDS_BYTES / 16 : (K + 1) * 64;
+  __shared__ double2 shared[LDS_VEC];
+  // Tasks: first the interior strips (1 .. nstrips-2) x their chunks, then the two edge strips
+  // (0 and nstrips-1) with their own, shorter chunks.
+  int task = blockIdx.x, sx, r0, r1;
+  if (task < A.n_interior_tasks) {
+    const int nint = A.nstrips - 2;
+    sx = 1 + task % nint;
+    r0 = (task / nint) * A.rows_per_chunk;
+    r1 = min(r0 + A.rows_per_chunk, A.ny);
+  } else {
+    task -= A.n_interior_tasks;
+    const int nedge = A.nstrips >= 2 ? 2 : 1;
+    sx = (task % nedge) == 0 ? 0 : A.nstrips - 1;
+    r0 = (task / nedge) * A.rows_per_chunk_edge;
+    r1 = min(r0 + A.rows_per_chunk_edge, A.ny);
+  }
   constexpr int HK = (K + 1) & ~1;
   constexpr int WOUT = 128 - 2 * HK;
   // A strip is an edge strip when any of its 128 columns is not an interior column.
   const int cfirst = sx * WOUT - HK, clast = cfirst + 127;
   if (cfirst < 1 || clast > A.nx - 2) {
-    Task<K, ALIGNED, DIV, true> t(A, gring, sx, cy);
+    Task<K, ALIGNED, DIV, true> t(A, shared, sx, r0, r1);
     t.run();
   } else {
-    Task<K, ALIGNED, DIV, false> t(A, gring, sx, cy);
+    Task<K, ALIGNED, DIV, false> t(A, shared, sx, r0, r1);
     t.run();
   }
 }
 
 template <int K>
-int launch_k(nsk_ctx *ctx, PoissonArgs &A, bool aligned, int div, int rows_per_chunk_hint) {
+int launch_k(nsk_ctx *ctx, PoissonArgs &A, bool aligned, int div, int rows_per_chunk_hint, int edge_percent) {
   constexpr int HK = (K + 1) & ~1;
   constexpr int WOUT = 128 - 2 * HK;
   A.nstrips = (A.nx - 1 + WOUT - 1) / WOUT;  // columns 0..nx-2; nx-1 rides with nx-2
+  // One wavefront per task, NSK_WAVES of them resident per SIMD: the launch is fastest when all
+  // tasks are resident at once (one round) and equally long.  The two edge strips carry the
+  // boundary-column work on top, so their chunks are shorter (edge_percent of the others').
+  // Automatic choice: the smallest chunk height whose task count still fits one round.
+  const int slots = ctx->num_simds * NSK_WAVES;
+  const int ep = edge_percent > 0 ? edge_percent : 75;
+  const int nint = A.nstrips > 2 ? A.nstrips - 2 : 0, nedge = A.nstrips >= 2 ? 2 : 1;
+  const int min_rows = 2 * K > 2 ? 2 * K : 2;
+  auto edge_rows = [&](int rpc) {
+    int rpe = (int)((long)rpc * ep / 100);
+    if (rpe < min_rows) rpe = min_rows;
+    return rpe > rpc ? rpc : rpe;
+  };
+  auto task_count = [&](int rpc) {
+    const int rpe = edge_rows(rpc);
+    return (long)nint * ((A.ny + rpc - 1) / rpc) + (long)nedge * ((A.ny + rpe - 1) / rpe);
+  };
   int rpc = rows_per_chunk_hint;
   if (rpc <= 0) {
-    // Aim at about 2048 tasks (8 waves per CU on 256 CUs) but keep the K halo
-    // rows at each chunk end a small fraction of the chunk.
-    int want_chunks = 2048 / A.nstrips;
-    if (want_chunks < 1) want_chunks = 1;
-    rpc = (A.ny + want_chunks - 1) / want_chunks;
-    if (rpc < 8 * K) rpc = 8 * K;
+    rpc = (int)(((long)A.ny * A.nstrips + slots - 1) / slots);
+    if (rpc < min_rows) rpc = min_rows;
+    while (rpc < A.ny && task_count(rpc) > slots) rpc++;
   }
   if (rpc < 2) rpc = 2;
+  const int rpe = edge_rows(rpc);
   A.rows_per_chunk = rpc;
   A.nchunks = (A.ny + rpc - 1) / rpc;
-  const unsigned tasks = (unsigned)A.nstrips * (unsigned)A.nchunks;
+  A.rows_per_chunk_edge = rpe;
+  A.nchunks_edge = (A.ny + rpe - 1) / rpe;
+  A.n_interior_tasks = nint * A.nchunks;
+  const unsigned tasks = (unsigned)task_count(rpc);
 #define NSK_LAUNCH(AL, DV) k_poisson<K, AL, DV><<<tasks, 64, 0, ctx->stream>>>(A)
   if (aligned) {
     if (div == DIV_FMA3) NSK_LAUNCH(true, DIV_FMA3);

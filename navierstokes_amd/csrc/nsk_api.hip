@@ -26,6 +26,9 @@ extern "C" int nsk_create(int device, nsk_ctx **out) {
   NSK_HIP(hipSetDevice(device));
   nsk_ctx *c = new nsk_ctx();
   c->device = device;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+    c->num_simds = 4 * cus;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
     nsk_set_error("nsk_create: hipStreamCreate failed");
     delete c;
@@ -83,6 +86,11 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
     ctx->poisson_rows = value;
     return 0;
   }
+  if (!strcmp(name, "poisson_edge_percent")) {
+    NSK_REQUIRE(value >= 0 && value <= 100, "poisson_edge_percent must be 0..100, got %d", value);
+    ctx->poisson_edge_percent = value;
+    return 0;
+  }
   if (!strcmp(name, "poisson_div")) {
     NSK_REQUIRE(value == -1 || value == 0 || value == 3 || value == 4,
                 "poisson_div must be -1 (automatic), 0, 3 or 4, got %d", value);
@@ -101,6 +109,10 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   }
   if (!strcmp(name, "poisson_rows")) {
     *value = ctx->poisson_rows;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_edge_percent")) {
+    *value = ctx->poisson_edge_percent;
     return 0;
   }
   if (!strcmp(name, "poisson_div")) {

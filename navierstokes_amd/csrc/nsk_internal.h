@@ -8,10 +8,11 @@
 
 #include "../../include/nsk.h"
 
-#define NSK_DEFAULT_POISSON_K 4
+#define NSK_DEFAULT_POISSON_K 5
 
 struct nsk_ctx {
   int device = 0;
+  int num_simds = 1024;  // 4 per compute unit
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;  // stream in use (own_stream or the caller's)
   // Reduction slot for max|.| (bit pattern of a non-negative double) and its
@@ -24,6 +25,7 @@ struct nsk_ctx {
   size_t pp_elems = 0;
   int poisson_k = 0;     // passes per launch, 0 = NSK_DEFAULT_POISSON_K (NSK_POISSON_K / nsk_set_option)
   int poisson_div = -1;  // -1 = automatic; 0 / 3 / 4 force a division form (testing)
+  int poisson_edge_percent = 0;  // rows per task of the edge strips in % of poisson_rows, 0 = default
   int poisson_rows = 0;  // rows per task chunk, 0 = automatic (NSK_POISSON_ROWS / nsk_set_option)
 };
 

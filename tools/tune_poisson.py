@@ -18,6 +18,7 @@ ap.add_argument("--ks", default="1,2,3,4,5,6,7,8")
 ap.add_argument("--rows", default="0")
 ap.add_argument("--launches", type=int, default=40)
 ap.add_argument("--div", type=int, default=-1)
+ap.add_argument("--edge", default="0")
 ap.add_argument("--dense", action="store_true", help="dense (unaligned) storage instead of pitched")
 a = ap.parse_args()
 
@@ -40,8 +41,9 @@ else:
     cp = c_params(p, ld_pr=ld, dp_embedded=1)
 ptr = lambda t: C.c_void_p(t.data_ptr())
 for k in [int(x) for x in a.ks.split(",")]:
-    for rows in [int(x) for x in a.rows.split(",")]:
+    for rows, edge in [(int(x), int(e)) for x in a.rows.split(",") for e in a.edge.split(",")]:
         ctx.set_option("poisson_k", k)
+        ctx.set_option("poisson_edge_percent", edge)
         ctx.set_option("poisson_rows", rows)
         ctx.set_option("poisson_div", a.div)
         ctx.ns_poisson_iters(ptr(Pr), ptr(dP), ptr(dv), C.byref(cp), 2 * k)
@@ -52,4 +54,4 @@ for k in [int(x) for x in a.ks.split(",")]:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / (a.launches * k)
-        print(f"K={k} rows={rows:4d}  {us:8.2f} us/pass  launch {us*k:8.1f} us  T_eff {40.0*nx*ny/us/1e3:9.1f} GB/s", flush=True)
+        print(f"K={k} rows={rows:4d} edge={edge:3d}  {us:8.2f} us/pass  launch {us*k:8.1f} us  T_eff {40.0*nx*ny/us/1e3:9.1f} GB/s", flush=True)
