@@ -5,3 +5,12 @@
 namespace nsk_poisson {
 template int launch_k<NSK_K>(nsk_ctx *, PoissonArgs &, bool, int, int, int);
 }  // namespace nsk_poisson
+
+#ifdef NSK_POISSON_TRACE
+#define NSK_CAT_(a, b) a##b
+#define NSK_CAT(a, b) NSK_CAT_(a, b)
+extern "C" int NSK_CAT(nsk_debug_trace_k, NSK_K)(unsigned long long *out, int ntasks) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nsk_poisson::nsk_trace_buf),
+                                  sizeof(unsigned long long) * 4 * (size_t)ntasks);
+}
+#endif

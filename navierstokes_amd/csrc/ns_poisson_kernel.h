@@ -571,10 +571,18 @@ struct Task {
   }
 };
 
+#ifdef NSK_POISSON_TRACE
+// Debug build only: per-task start/end clock (100 MHz) and hardware placement.
+static __device__ unsigned long long nsk_trace_buf[NSK_POISSON_TRACE * 4];
+#endif
+
 template <int K, bool ALIGNED, int DIV>
 __global__ void __launch_bounds__(64) NSK_WAVES_ATTR k_poisson(PoissonArgs A) {
   constexpr int LDS_VEC = ALIGNED ? DmaGeometry<K>::LDS_BYTES / 16 : (K + 1) * 64;
   __shared__ double2 shared[LDS_VEC];
+#ifdef NSK_POISSON_TRACE
+  const unsigned long long trace_t0 = wall_clock64();
+#endif
   // Tasks: first the interior strips (1 .. nstrips-2) x their chunks, then the two edge strips
   // (0 and nstrips-1) with their own, shorter chunks.
   int task = blockIdx.x, sx, r0, r1;
@@ -601,6 +609,14 @@ __global__ void __launch_bounds__(64) NSK_WAVES_ATTR k_poisson(PoissonArgs A) {
     Task<K, ALIGNED, DIV, false> t(A, shared, sx, r0, r1);
     t.run();
   }
+#ifdef NSK_POISSON_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < NSK_POISSON_TRACE) {
+    nsk_trace_buf[blockIdx.x * 4 + 0] = trace_t0;
+    nsk_trace_buf[blockIdx.x * 4 + 1] = wall_clock64();
+    nsk_trace_buf[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    nsk_trace_buf[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+#endif
 }
 
 template <int K>
