@@ -232,6 +232,21 @@ int nsk_bub_solve_pressure(nsk_ctx *ctx, double *p, const double *tmp1,
                            const double *tmp2, const double *rt, double beta, double dx,
                            double dy, int nx, int ny, int maxit, double maxError,
                            int *sweeps_out, double *change_out);
+/* Red/black SOR: solve_pressure_kernel_red!/black! code3_perf_gpu.jl:129-183 with the loop
+ * :609-617 (same kernels in scripts/tests/test_solve_pressure_gpu.jl:6-61).  Ordinary grids,
+ * scales past one workgroup; NOT the lexicographic update order of nsk_bub_solve_pressure
+ * (results agree with it only to the iteration error).  Double precision.  Synchronous. */
+int nsk_bub_solve_pressure_rb(nsk_ctx *ctx, double *p, const double *tmp1,
+                              const double *tmp2, const double *rt, double beta, double dx,
+                              double dy, int nx, int ny, int maxit, double maxError,
+                              int *sweeps_out, double *change_out);
+/* update_dPdτ! + update_p! code1_perf_gpu.jl:98-118 with the loop :228-242: damped
+ * pseudo-transient iteration of the variable-density pressure equation; dPdtau ((nx+2)x(ny+2))
+ * persists between calls.  Double precision.  Synchronous. */
+int nsk_bub_pt_pressure(nsk_ctx *ctx, double *p, double *dPdtau, const double *tmp1,
+                        const double *rt, double dtau, double damp, double dx, double dy,
+                        int nx, int ny, int maxit, double maxError, int *iters_out,
+                        double *change_out);
 /* correct_uvel! + correct_vvel!  DNS.jl:190-202 / code1.m:80-86 (u or v may be NULL) */
 int nsk_bub_correct_vel(nsk_ctx *ctx, double *u, double *v, const double *ut,
                         const double *vt, const double *p, const double *r, double dt,

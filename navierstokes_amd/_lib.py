@@ -77,6 +77,8 @@ _SIGS = {
     "nsk_bub_set_boundary": [_P, _P, _D, _I, _I],
     "nsk_bub_compute_sources": [_P, _P, _P, _P, _P, _D, _D, _D, _I, _I],
     "nsk_bub_solve_pressure": [_P, _P, _P, _P, _D, _D, _D, _I, _I, _I, _D, c_int_p, c_double_p],
+    "nsk_bub_solve_pressure_rb": [_P, _P, _P, _P, _D, _D, _D, _I, _I, _I, _D, c_int_p, c_double_p],
+    "nsk_bub_pt_pressure": [_P, _P, _P, _P, _D, _D, _D, _D, _I, _I, _I, _D, c_int_p, c_double_p],
     "nsk_bub_correct_vel": [_P, _P, _P, _P, _P, _P, _D, _D, _D, _I, _I],
     "nsk_bub_advect_density": [_P, _P, _P, _P, _D, _D, _D, _D, _I, _I],
     "nsk_bub_velocity": [_P, _P, _P, _P, _I, _I],

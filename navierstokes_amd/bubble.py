@@ -67,6 +67,16 @@ class DNSParams:
     maxit: int = 400
     maxerr: float = 1e-3
     beta: float = 1.2
+    # "sor": lexicographic SOR (DNS.jl:83-93 / code1.m:68-78, the reference's result);
+    # "redblack": red/black SOR (code3_perf_gpu.jl:129-183); "pt": damped pseudo-transient
+    # iteration (code1_perf_gpu.jl:98-118, 228-242) with damp / dtau = cfl_tau*dy (:166,180)
+    pressure_solver: str = "sor"
+    damp: float = 0.72
+    cfl_tau: float = 0.9 / 2 ** 0.5
+
+    @property
+    def dtau(self):
+        return self.cfl_tau * self.dy
 
     @property
     def dx(self):
@@ -104,6 +114,7 @@ class DNS:
         self.ut, self.vt = A(nx + 1, ny + 2), A(nx + 2, ny + 1)
         self.uu, self.vv = A(nx + 1, ny + 1), A(nx + 1, ny + 1)
         self.tmp1, self.tmp2 = A(nx + 2, ny + 2), A(nx + 2, ny + 2)
+        self.dPdtau = A(nx + 2, ny + 2)  # code1_perf_gpu.jl:183 (used by pressure_solver="pt")
         self.xc, self.yc = A(nx + 2), A(ny + 2)
         self.xc.set(cell_centres(nx, q.dx))
         self.yc.set(cell_centres(ny, q.dy))
@@ -124,8 +135,17 @@ class DNS:
         k.bub_compute_sources(self.tmp1.ptr, self.tmp2.ptr, self.rhot.ptr, self.ut.ptr, self.vt.ptr,
                               q.dt, q.dx, q.dy, nx, ny)
         sw = C.c_int(0)
-        k.bub_solve_pressure(self.p.ptr, self.tmp1.ptr, self.tmp2.ptr, self.rhot.ptr, q.beta, q.dx, q.dy,
-                             nx, ny, q.maxit, q.maxerr, C.byref(sw), None)
+        if q.pressure_solver == "sor":
+            k.bub_solve_pressure(self.p.ptr, self.tmp1.ptr, self.tmp2.ptr, self.rhot.ptr, q.beta, q.dx, q.dy,
+                                 nx, ny, q.maxit, q.maxerr, C.byref(sw), None)
+        elif q.pressure_solver == "redblack":
+            k.bub_solve_pressure_rb(self.p.ptr, self.tmp1.ptr, self.tmp2.ptr, self.rhot.ptr, q.beta, q.dx, q.dy,
+                                    nx, ny, q.maxit, q.maxerr, C.byref(sw), None)
+        elif q.pressure_solver == "pt":
+            k.bub_pt_pressure(self.p.ptr, self.dPdtau.ptr, self.tmp1.ptr, self.rhot.ptr, q.dtau, q.damp,
+                              q.dx, q.dy, nx, ny, q.maxit, q.maxerr, C.byref(sw), None)
+        else:
+            raise ValueError(f"unknown pressure_solver {q.pressure_solver!r}")
         k.bub_correct_vel(self.u.ptr, self.v.ptr, self.ut.ptr, self.vt.ptr, self.p.ptr, self.rho.ptr,
                           q.dt, q.dx, q.dy, nx, ny)
         self.rho_o.copy_from(self.rho)

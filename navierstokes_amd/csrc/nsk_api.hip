@@ -58,6 +58,8 @@ extern "C" int nsk_destroy(nsk_ctx *c) {
   if (c->red_host) (void)hipHostFree(c->red_host);
   if (c->pp_pr) (void)hipFree(c->pp_pr);
   if (c->pp_dp) (void)hipFree(c->pp_dp);
+  if (c->hist_dev) (void)hipFree(c->hist_dev);
+  if (c->hist_host) (void)hipHostFree(c->hist_host);
   delete c;
   return 0;
 }

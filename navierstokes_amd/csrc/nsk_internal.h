@@ -5,6 +5,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 
 #include "../../include/nsk.h"
 
@@ -23,6 +24,9 @@ struct nsk_ctx {
   // (re)allocated on demand by the fused entry points.
   double *pp_pr = nullptr, *pp_dp = nullptr;
   size_t pp_elems = 0;
+  // Per-iteration max|old-new| history of the batched iterative solvers (device + pinned host).
+  unsigned long long *hist_dev = nullptr, *hist_host = nullptr;
+  size_t hist_cap = 0;
   int poisson_k = 0;     // passes per launch, 0 = NSK_DEFAULT_POISSON_K (NSK_POISSON_K / nsk_set_option)
   int poisson_div = -1;  // -1 = automatic; 0 / 3 / 4 force a division form (testing)
   int poisson_edge_percent = 0;  // rows per task of the edge strips in % of poisson_rows, 0 = default

@@ -221,6 +221,72 @@ int bub_solve_pressure(double *p, const double *tmp1, const double *tmp2, const 
   return it > maxit ? maxit : it;
 }
 
+/* code3_perf_gpu.jl:129-183 (red then black colour sweep) with its loop :609-617 (and
+ * scripts/tests/test_solve_pressure_gpu.jl:6-61): in-place SOR where all cells with i+j even
+ * are updated first, then all cells with i+j odd; stop when max|old-new| < maxError.  In double
+ * precision (the reference's CUDA.zeros arrays are Float32).  Not the lexicographic order of
+ * bub_solve_pressure: results differ from it by the iteration error. */
+int bub_solve_pressure_rb(double *p, const double *tmp1, const double *tmp2, const double *rt,
+                          double beta, double dx, double dy, int nx, int ny, int maxit,
+                          double maxError, double *last_change) {
+  size_t n = (size_t)(nx + 2) * (ny + 2);
+  double *old = (double *)malloc(n * sizeof(double));
+  int it;
+  double ch = 0.0;
+  for (it = 1; it <= maxit; it++) {
+    memcpy(old, p, n * sizeof(double));
+    for (int colour = 0; colour < 2; colour++)
+      for (int j = 2; j <= ny + 1; j++)
+        for (int i = 2; i <= nx + 1; i++) {
+          if ((i + j) % 2 != colour) continue;
+          P(i, j) = (1.0 - beta) * P(i, j) +
+                    beta * B2(tmp2, nx + 2, i, j) *
+                        ((1.0 / dx) * (P(i + 1, j) / (dx * (RT(i + 1, j) + RT(i, j))) +
+                                       P(i - 1, j) / (dx * (RT(i - 1, j) + RT(i, j)))) +
+                         (1.0 / dy) * (P(i, j + 1) / (dy * (RT(i, j + 1) + RT(i, j))) +
+                                       P(i, j - 1) / (dy * (RT(i, j - 1) + RT(i, j)))) -
+                         B2(tmp1, nx + 2, i, j));
+        }
+    ch = max_abs_diff(old, p, n);
+    if (ch < maxError) break;
+  }
+  free(old);
+  if (last_change) *last_change = ch;
+  return it > maxit ? maxit : it;
+}
+
+/* code1_perf_gpu.jl:98-118 (update_dPdtau!, update_p!) with its loop :228-242: damped
+ * pseudo-transient iteration for the variable-density pressure equation; every iteration is
+ * two whole-array maps.  dPdtau persists across calls like the reference's array.  In double
+ * precision.  Returns the iterations performed. */
+int bub_pt_pressure(double *p, double *dPdtau, const double *tmp1, const double *rt, double dtau,
+                    double damp, double dx, double dy, int nx, int ny, int maxit, double maxError,
+                    double *last_change) {
+  size_t n = (size_t)(nx + 2) * (ny + 2);
+  double *old = (double *)malloc(n * sizeof(double));
+  int it;
+  double ch = 0.0;
+  for (it = 1; it <= maxit; it++) {
+    memcpy(old, p, n * sizeof(double));
+    for (int j = 2; j <= ny + 1; j++)
+      for (int i = 2; i <= nx + 1; i++)
+        B2(dPdtau, nx + 2, i, j) =
+            B2(dPdtau, nx + 2, i, j) * (1.0 - damp) +
+            dtau * ((1.0 / dx) * ((P(i + 1, j) - P(i, j)) / (dx * (RT(i + 1, j) + RT(i, j))) -
+                                  (P(i, j) - P(i - 1, j)) / (dx * (RT(i - 1, j) + RT(i, j)))) +
+                    (1.0 / dy) * ((P(i, j + 1) - P(i, j)) / (dy * (RT(i, j + 1) + RT(i, j))) -
+                                  (P(i, j) - P(i, j - 1)) / (dy * (RT(i, j - 1) + RT(i, j)))) -
+                    B2(tmp1, nx + 2, i, j));
+    for (int j = 2; j <= ny + 1; j++)
+      for (int i = 2; i <= nx + 1; i++) P(i, j) = P(i, j) + dtau * B2(dPdtau, nx + 2, i, j);
+    ch = max_abs_diff(old, p, n);
+    if (ch < maxError) break;
+  }
+  free(old);
+  if (last_change) *last_change = ch;
+  return it > maxit ? maxit : it;
+}
+
 /* code1.m:80-86, code3_fun.jl:126-143 */
 void bub_correct_uvel(double *u, const double *ut, const double *p, const double *r, double dt,
                       double dx, int nx, int ny) {

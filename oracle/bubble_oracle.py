@@ -35,7 +35,7 @@ class BubbleOracle:
     def __init__(self):
         build()
         self.lib = C.CDLL(os.path.join(_HERE, "libnsoracle.so"))
-        for n in ("bub_solve_pressure", "bub_construct_den", "bub_move_front", "bub_regrid_front",
+        for n in ("bub_solve_pressure", "bub_solve_pressure_rb", "bub_pt_pressure", "bub_construct_den", "bub_move_front", "bub_regrid_front",
                   "bub_code1_step", "bub_code3_step"):
             getattr(self.lib, n).restype = _I
 
@@ -73,8 +73,33 @@ class OracleDNS:
         self.o.set_density(self.rho, None, q.xcenter, q.ycenter, cell_centres(nx, q.dx), cell_centres(ny, q.dy),
                            q.rad, q.rho2, 0.0, nx, ny)
 
+    def _step_with(self, solver) -> int:
+        """The body of bub_code1_step from its parts, with another pressure solver."""
+        q, o, nx, ny = self.q, self.o, self.q.nx, self.q.ny
+        o.set_tangential(self.u, self.v, q.usouth, q.unorth, q.vwest, q.veast, nx, ny)
+        o.temp_uvel(self.ut, self.u, self.v, self.rho, q.dt, q.dx, q.dy, q.gx, q.m0, nx, ny)
+        o.temp_vvel(self.vt, self.u, self.v, self.rho, q.dt, q.dx, q.dy, q.gy, q.m0, nx, ny)
+        o.set_boundary(self.rhot, self.rho, 1000.0, nx, ny)
+        o.compute_sources(self.tmp1, self.tmp2, self.rhot, self.ut, self.vt, q.dt, q.dx, q.dy, nx, ny)
+        if solver == "redblack":
+            it = o.solve_pressure_rb(self.p, self.tmp1, self.tmp2, self.rhot, q.beta, q.dx, q.dy, nx, ny,
+                                     q.maxit, q.maxerr, None)
+        else:
+            if not hasattr(self, "dPdtau"):
+                self.dPdtau = F(nx + 2, ny + 2)
+            it = o.pt_pressure(self.p, self.dPdtau, self.tmp1, self.rhot, q.dtau, q.damp, q.dx, q.dy, nx, ny,
+                               q.maxit, q.maxerr, None)
+        o.correct_uvel(self.u, self.ut, self.p, self.rho, q.dt, q.dx, nx, ny)
+        o.correct_vvel(self.v, self.vt, self.p, self.rho, q.dt, q.dy, nx, ny)
+        self.rho_o[:] = self.rho
+        o.advect_density(self.rho, self.rho_o, self.u, self.v, q.dt, q.dx, q.dy, q.m0, nx, ny)
+        o.velocity(self.uu, self.vv, self.u, self.v, nx, ny)
+        return it
+
     def step(self) -> int:
         q = self.q
+        if getattr(q, "pressure_solver", "sor") != "sor":
+            return self._step_with(q.pressure_solver)
         it = self.o.code1_step(self.u, self.v, self.p, self.rho, self.ut, self.vt, self.tmp1, self.tmp2, self.rhot,
                                self.rho_o, q.dt, q.dx, q.dy, q.gx, q.gy, q.m0, q.usouth, q.unorth, q.vwest, q.veast,
                                q.beta, q.maxit, q.maxerr, q.nx, q.ny)

@@ -173,6 +173,69 @@ def test_dns_steps():
         assert same_bits(getattr(g, k).get(), getattr(o, k)), k
 
 
+@pytest.mark.parametrize("nx,ny", GRIDS + [(300, 257)])
+def test_scalable_pressure_solvers(gpu, bo, nx, ny):
+    """Red/black SOR (code3_perf_gpu.jl:129-183) and the pseudo-transient iteration
+    (code1_perf_gpu.jl:98-118): a fixed number of iterations, then to convergence; iteration
+    count, last change and fields equal the oracle's bit for bit."""
+    rng = np.random.default_rng(nx * 17 + ny)
+    dx, dy = 1.0 / nx, 1.3 / ny
+    p, t1 = rf(rng, nx + 2, ny + 2), rf(rng, nx + 2, ny + 2) * 10.0
+    rt = rf(rng, nx + 2, ny + 2, 1.0)
+    t2 = np.zeros_like(p)
+    bo.set_boundary(rt, rt.copy(order="F"), 1000.0, nx, ny)
+    bo.compute_sources(np.zeros_like(p), t2, rt, rf(rng, nx + 1, ny + 2), rf(rng, nx + 2, ny + 1), 1e-3, dx, dy, nx, ny)
+    dt1, dt2, drt = Dev(t1), Dev(t2), Dev(rt)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    D = C.c_double
+    # red/black: 3 and 11 sweeps (odd: crosses a batch boundary), then to a tolerance
+    prb = p.copy(order="F")
+    dprb = Dev(prb)
+    for maxit, tol in ((3, 0.0), (11, 0.0), (400, 1e-4 * np.abs(t1).max() * dx * dx)):
+        sw, ch, chr_ = C.c_int(0), D(0.0), D(0.0)
+        gpu.bub_solve_pressure_rb(dprb.ptr, dt1.ptr, dt2.ptr, drt.ptr, 1.2, dx, dy, nx, ny, maxit, tol, C.byref(sw), C.byref(ch))
+        it = bo.lib.bub_solve_pressure_rb(vp(prb), vp(t1), vp(t2), vp(rt), D(1.2), D(dx), D(dy), nx, ny, maxit, D(tol), C.byref(chr_))
+        assert sw.value == it and ch.value == chr_.value, (maxit, sw.value, it, ch.value, chr_.value)
+        assert same_bits(dprb.get(), prb)
+    # pseudo-transient
+    ppt, dP = p.copy(order="F"), np.zeros_like(p)
+    dppt, ddP = Dev(ppt), Dev(dP)
+    dtau = 0.9 / np.sqrt(2.0) * min(dx, dy)
+    for maxit, tol in ((5, 0.0), (9, 0.0), (300, 1e-3 * np.abs(t1).max() * dtau * dtau)):
+        sw, ch, chr_ = C.c_int(0), D(0.0), D(0.0)
+        gpu.bub_pt_pressure(dppt.ptr, ddP.ptr, dt1.ptr, drt.ptr, dtau, 0.72, dx, dy, nx, ny, maxit, tol, C.byref(sw), C.byref(ch))
+        it = bo.lib.bub_pt_pressure(vp(ppt), vp(dP), vp(t1), vp(rt), D(dtau), D(0.72), D(dx), D(dy), nx, ny, maxit, D(tol), C.byref(chr_))
+        assert sw.value == it and ch.value == chr_.value, (maxit, sw.value, it, ch.value, chr_.value)
+        assert same_bits(dppt.get(), ppt) and same_bits(ddP.get(), dP)
+
+
+def test_solver_nan_runs_to_maxit(gpu, bo):
+    """A NaN change never satisfies `< maxError`: both solvers run all maxit iterations."""
+    nx = ny = 6
+    p = np.asfortranarray(np.zeros((nx + 2, ny + 2)))
+    p[3, 3] = np.nan
+    one = np.asfortranarray(np.ones((nx + 2, ny + 2)))
+    dp_, d1 = Dev(p), Dev(one)
+    sw, ch = C.c_int(0), C.c_double(0.0)
+    gpu.bub_solve_pressure_rb(dp_.ptr, d1.ptr, d1.ptr, d1.ptr, 1.2, 0.1, 0.1, nx, ny, 19, 1e-3, C.byref(sw), C.byref(ch))
+    assert sw.value == 19 and np.isnan(ch.value)
+    ddP = Dev(np.asfortranarray(np.zeros((nx + 2, ny + 2))))
+    gpu.bub_pt_pressure(dp_.ptr, ddP.ptr, d1.ptr, d1.ptr, 0.01, 0.72, 0.1, 0.1, nx, ny, 10, 1e-3, C.byref(sw), C.byref(ch))
+    assert sw.value == 10 and np.isnan(ch.value)
+
+
+@pytest.mark.parametrize("solver", ["redblack", "pt"])
+def test_dns_steps_other_solvers(solver):
+    """The drop problem with the scalable pressure solvers: 6 steps, bit-identical to the oracle
+    run with the same solver."""
+    q = DNSParams(pressure_solver=solver, maxit=200 if solver == "redblack" else 3000)
+    g, o = DNS(q), OracleDNS(q)
+    for _ in range(6):
+        assert g.step() == o.step()
+    for k in ("rho", "u", "v", "p", "uu", "vv"):
+        assert same_bits(getattr(g, k).get(), getattr(o, k)), k
+
+
 def test_code3_steps():
     """scripts/code3_fun.jl at its sizes (32 x 32, Nf = 100): 12 steps incl. front regridding."""
     q = Code3Params()
