@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--halo", type=int, default=32, help="halo rows = passes between exchanges (N>1)")
     ap.add_argument("--passes", type=int, default=0, help="passes per step (default nchk)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--time-steps", type=int, default=0,
+    ap.add_argument("--time-steps", type=int, default=3,
                     help="additionally run this many whole reference time steps from the IC (N=1)")
     a = ap.parse_args()
 
@@ -183,15 +183,18 @@ def main():
     if rank == 0 and world == 1 and a.time_steps > 0:
         from navierstokes_amd.ns import NavierStokes
         sim = NavierStokes(p1, device=f"cuda:{local}")
-        its = []
+        its, secs = [], []
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
         for _ in range(a.time_steps):
+            t0 = time.perf_counter()
             its.append(sim.step())
-        torch.cuda.synchronize()
-        tts = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            secs.append(time.perf_counter() - t0)
+        tts = sum(secs)
         out["time_steps"] = {"steps": a.time_steps, "steps_per_s": a.time_steps / tts,
-                             "poisson_iters": its, "from": "reference initial condition"}
+                             "poisson_iters": its, "seconds": secs,
+                             "us_per_pass_whole_step": [s_ / i * 1e6 for s_, i in zip(secs, its)],
+                             "from": "reference initial condition"}
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(p1)
     if rank == 0:

@@ -172,6 +172,37 @@ class NavierStokes:
         a = self.dPrdtau.get()
         return np.asfortranarray(a[1:-1, 1:-1]) if self.pitched else a
 
+    # -- restart files --------------------------------------------------------------------
+    # What the next step reads from the previous one: Vx, Vy, C (advected), Pr, and dPrdτ,
+    # which the time loop never resets (NavierStokes.jl:58,85).  The reference saves only
+    # Pr, Vx, Vy, C (:109), so a run continued from its .mat files is not the same run;
+    # this file is.
+    RESTART_KEYS = ("Pr", "Vx", "Vy", "C", "dPrdtau")
+
+    def save_restart(self, path: str) -> None:
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        p = self.p
+        np.savez(path, **self.host_fields(), dPrdtau=self.dPrdtau_host(), it=self.it,
+                 grid=np.array([p.nx, p.ny]), scalars=np.array([p.dx, p.dy, p.dt, p.dtau, p.damp, p.rho, p.mu]))
+
+    def load_restart(self, path: str) -> None:
+        with np.load(path, allow_pickle=False) as z:
+            p = self.p
+            if tuple(z["grid"]) != (p.nx, p.ny):
+                raise ValueError(f"restart file is for a {tuple(z['grid'])} grid, this run is {(p.nx, p.ny)}")
+            want = np.array([p.dx, p.dy, p.dt, p.dtau, p.damp, p.rho, p.mu])
+            if not np.array_equal(z["scalars"], want):
+                raise ValueError("restart file was written with other parameters (dx, dy, dt, dtau, damp, rho, mu)")
+            for k in ("Pr", "Vx", "Vy", "C"):
+                getattr(self, k).set(np.asfortranarray(z[k]))
+            d = np.asfortranarray(z["dPrdtau"])
+            if self.pitched:
+                full = np.zeros((p.nx, p.ny), order="F")
+                full[1:-1, 1:-1] = d
+                d = full
+            self.dPrdtau.set(d)
+            self.it = int(z["it"])
+
 
 def save_mat(path: str, fields: dict, dx: float, dy: float) -> None:
     """`matwrite("out_vis/step_N.mat", Dict("Pr","Vx","Vy","C","dx","dy"))` (NavierStokes.jl:75,109)."""
@@ -182,14 +213,17 @@ def save_mat(path: str, fields: dict, dx: float, dy: float) -> None:
 
 def runme(n: int = 1, do_vis: bool = True, do_save: bool = False, *, script: str = "NavierStokes_Re6",
           nt: Optional[int] = None, device: str = "cuda:0", out_dir: str = "out_vis",
-          mode: str = "fused", verbose: bool = True, **overrides) -> NavierStokes:
+          mode: str = "fused", verbose: bool = True, restart_from: Optional[str] = None,
+          restart_every: int = 0, **overrides) -> NavierStokes:
     """`runme(; n, do_vis, do_save)` of the reference drivers.  do_vis is accepted for interface
     compatibility; plotting is left to vis/vis_navier_stokes.m on the saved .mat files."""
     p = ns_params(script, n=n, **overrides)
     sim = NavierStokes(p, device=device, mode=mode)
-    if do_save:
+    if restart_from:
+        sim.load_restart(restart_from)
+    elif do_save:
         save_mat(os.path.join(out_dir, "step_0.mat"), sim.host_fields(), p.dx, p.dy)
-    for it in range(1, (nt if nt is not None else p.nt) + 1):
+    for it in range(sim.it + 1, (nt if nt is not None else p.nt) + 1):
         if verbose:
             print(f"#it = {it}")
         sim.step()
@@ -198,4 +232,6 @@ def runme(n: int = 1, do_vis: bool = True, do_save: bool = False, *, script: str
                 print(f"  #iter = {i}, err = {e:1.3e}")
         if do_save and it % p.nsave == 0:
             save_mat(os.path.join(out_dir, f"step_{it}.mat"), sim.host_fields(), p.dx, p.dy)
+        if restart_every and it % restart_every == 0:
+            sim.save_restart(os.path.join(out_dir, "restart.npz"))
     return sim

@@ -52,3 +52,21 @@ def test_full_rows_switch():
     got = sim.host_fields()
     for k in ("Pr", "Vx", "Vy", "C"):
         assert same_bits(got[k], getattr(ref, k)), k
+
+
+def test_restart_file_continues_the_same_run(tmp_path):
+    """2 + 2 steps through a restart file (which carries dPrdτ, unlike the reference's .mat
+    output) equal 4 steps in one go, bit for bit; a file for another grid is refused."""
+    from navierstokes_amd.ns import runme
+    kw = dict(script="NavierStokes", nx=47, ny=79, verbose=False, out_dir=str(tmp_path))
+    whole = runme(nt=4, **kw)
+    runme(nt=2, restart_every=2, **kw)
+    cont = runme(nt=4, restart_from=str(tmp_path / "restart.npz"), **kw)
+    assert cont.it == 4
+    a, b = whole.host_fields(), cont.host_fields()
+    for k in a:
+        assert same_bits(a[k], b[k]), k
+    assert same_bits(whole.dPrdtau_host(), cont.dPrdtau_host())
+    other = NavierStokes(ns_params("NavierStokes", nx=31, ny=79))
+    with pytest.raises(ValueError):
+        other.load_restart(str(tmp_path / "restart.npz"))
