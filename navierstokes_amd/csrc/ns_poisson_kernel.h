@@ -26,6 +26,7 @@ struct PoissonArgs {
   int nstrips, nchunks, rows_per_chunk;   // interior strips: chunks and rows per chunk
   int nchunks_edge, rows_per_chunk_edge;  // the first and the last strip do more work per row
   int n_interior_tasks;
+  int xcd_bands;  // nonzero: XCD-aware task numbering
   int xbc_rows;            // rows r < xbc_rows (0-based) receive the x-Neumann condition
   int phys_bottom, phys_top;
   double dx, dy, rho_dt, keep, dtau, topval;
@@ -587,6 +588,14 @@ __global__ void __launch_bounds__(64) NSK_WAVES_ATTR k_poisson(PoissonArgs A) {
   // (0 and nstrips-1) with their own, shorter chunks.
   int task = blockIdx.x, sx, r0, r1;
   if (task < A.n_interior_tasks) {
+    if (A.xcd_bands) {
+      // Workgroup i runs on XCD i % 8, each with its own L2.  Give every XCD a contiguous band
+      // of chunks over all strips, so that tasks that read the same halo columns (and rows)
+      // share an L2: task t is the (t / 8)-th task of band t % 8.
+      const int base = A.n_interior_tasks >> 3, rem = A.n_interior_tasks & 7;
+      const int x = task & 7;
+      task = x * base + min(x, rem) + (task >> 3);
+    }
     const int nint = A.nstrips - 2;
     sx = 1 + task % nint;
     r0 = (task / nint) * A.rows_per_chunk;
@@ -654,6 +663,7 @@ int launch_k(nsk_ctx *ctx, PoissonArgs &A, bool aligned, int div, int rows_per_c
   A.rows_per_chunk_edge = rpe;
   A.nchunks_edge = (A.ny + rpe - 1) / rpe;
   A.n_interior_tasks = nint * A.nchunks;
+  A.xcd_bands = ctx->poisson_xcd;
   const unsigned tasks = (unsigned)task_count(rpc);
 #define NSK_LAUNCH(AL, DV) k_poisson<K, AL, DV><<<tasks, 64, 0, ctx->stream>>>(A)
   if (aligned) {

@@ -88,6 +88,10 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
     ctx->poisson_rows = value;
     return 0;
   }
+  if (!strcmp(name, "poisson_xcd")) {
+    ctx->poisson_xcd = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "poisson_edge_percent")) {
     NSK_REQUIRE(value >= 0 && value <= 100, "poisson_edge_percent must be 0..100, got %d", value);
     ctx->poisson_edge_percent = value;
@@ -111,6 +115,10 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   }
   if (!strcmp(name, "poisson_rows")) {
     *value = ctx->poisson_rows;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_xcd")) {
+    *value = ctx->poisson_xcd;
     return 0;
   }
   if (!strcmp(name, "poisson_edge_percent")) {

@@ -30,6 +30,7 @@ struct nsk_ctx {
   int poisson_k = 0;     // passes per launch, 0 = NSK_DEFAULT_POISSON_K (NSK_POISSON_K / nsk_set_option)
   int poisson_div = -1;  // -1 = automatic; 0 / 3 / 4 force a division form (testing)
   int poisson_edge_percent = 0;  // rows per task of the edge strips in % of poisson_rows, 0 = default
+  int poisson_xcd = 1;   // XCD-aware task numbering of the Poisson kernel (0 = plain)
   int poisson_rows = 0;  // rows per task chunk, 0 = automatic (NSK_POISSON_ROWS / nsk_set_option)
 };
 

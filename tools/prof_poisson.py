@@ -14,6 +14,7 @@ from navierstokes_amd.ns import _pitch, c_params
 ap = argparse.ArgumentParser()
 ap.add_argument("--k", type=int, default=4)
 ap.add_argument("--rows", type=int, default=0)
+ap.add_argument("--xcd", type=int, default=1)
 ap.add_argument("--launches", type=int, default=20)
 ap.add_argument("--copy", action="store_true", help="also run a plain device copy of the same footprint")
 a = ap.parse_args()
@@ -33,6 +34,7 @@ cp = c_params(p, ld_pr=ld, dp_embedded=1)
 ptr = lambda t: C.c_void_p(t.data_ptr())
 ctx.set_option("poisson_k", a.k)
 ctx.set_option("poisson_rows", a.rows)
+ctx.set_option("poisson_xcd", a.xcd)
 ctx.ns_poisson_iters(ptr(Pr), ptr(dP), ptr(dv), C.byref(cp), a.k * a.launches)
 torch.cuda.synchronize()
 if a.copy:

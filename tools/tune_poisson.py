@@ -16,9 +16,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=16)
 ap.add_argument("--ks", default="1,2,3,4,5,6,7,8")
 ap.add_argument("--rows", default="0")
-ap.add_argument("--launches", type=int, default=40)
+ap.add_argument("--launches", type=int, default=200)
 ap.add_argument("--div", type=int, default=-1)
 ap.add_argument("--edge", default="0")
+ap.add_argument("--xcd", default="1")
 ap.add_argument("--dense", action="store_true", help="dense (unaligned) storage instead of pitched")
 a = ap.parse_args()
 
@@ -40,10 +41,15 @@ else:
     dP = torch.zeros((ny, ld), dtype=torch.float64, device="cuda")
     cp = c_params(p, ld_pr=ld, dp_embedded=1)
 ptr = lambda t: C.c_void_p(t.data_ptr())
+# the clocks of an idle GPU take a while to come up: about 0.2 s of work before any timing
+ctx.ns_poisson_iters(ptr(Pr), ptr(dP), ptr(dv), C.byref(cp), 8000)
+torch.cuda.synchronize()
 for k in [int(x) for x in a.ks.split(",")]:
-    for rows, edge in [(int(x), int(e)) for x in a.rows.split(",") for e in a.edge.split(",")]:
+    for rows, edge, xcd in [(int(x), int(e), int(c)) for x in a.rows.split(",") for e in a.edge.split(",")
+                            for c in a.xcd.split(",")]:
         ctx.set_option("poisson_k", k)
         ctx.set_option("poisson_edge_percent", edge)
+        ctx.set_option("poisson_xcd", xcd)
         ctx.set_option("poisson_rows", rows)
         ctx.set_option("poisson_div", a.div)
         ctx.ns_poisson_iters(ptr(Pr), ptr(dP), ptr(dv), C.byref(cp), 2 * k)
@@ -54,4 +60,4 @@ for k in [int(x) for x in a.ks.split(",")]:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / (a.launches * k)
-        print(f"K={k} rows={rows:4d} edge={edge:3d}  {us:8.2f} us/pass  launch {us*k:8.1f} us  T_eff {40.0*nx*ny/us/1e3:9.1f} GB/s", flush=True)
+        print(f"K={k} rows={rows:4d} edge={edge:3d} xcd={xcd}  {us:8.2f} us/pass  launch {us*k:8.1f} us  T_eff {40.0*nx*ny/us/1e3:9.1f} GB/s", flush=True)
