@@ -67,10 +67,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=16, help="runme(n=...): nx=160n-1, ny=256n-1 per GPU")
-    ap.add_argument("--halo", type=int, default=32, help="halo rows = passes between exchanges (N>1)")
+    ap.add_argument("--scale", dest="n", type=int, default=16, help="runme(n=...): nx=160n-1, ny=256n-1 per GPU")
+    ap.add_argument("--halo", type=int, default=64, help="halo rows = passes between exchanges (N>1)")
     ap.add_argument("--passes", type=int, default=0, help="passes per step (default nchk)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="rehearsal: all ranks share cuda:0 (needs --backend gloo; not a measurement)")
     ap.add_argument("--time-steps", type=int, default=3,
                     help="additionally run this many whole reference time steps from the IC (N=1)")
     a = ap.parse_args()
@@ -88,10 +91,15 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    if a.one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     p1 = ns_params("NavierStokes_Re6", n=a.n)                   # one GPU's slab
     nx, ny_loc = p1.nx, p1.ny
@@ -132,7 +140,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
