@@ -70,3 +70,18 @@ def test_restart_file_continues_the_same_run(tmp_path):
     other = NavierStokes(ns_params("NavierStokes", nx=31, ny=79))
     with pytest.raises(ValueError):
         other.load_restart(str(tmp_path / "restart.npz"))
+
+
+def test_steps_benchmark_grid():
+    """Two whole time steps on the benchmark grid (2559 x 4095, Re = 1e6 parameters) with the
+    Poisson loop cut to 60 passes (check every 30) so the oracle finishes in seconds."""
+    p = ns_params("NavierStokes_Re6", n=16).with_(niter=60, nchk=30)
+    sim, ref = NavierStokes(p), OracleSim(p)
+    for _ in range(2):
+        assert sim.step() == ref.step()
+        assert sim.iter_evo == ref.iter_evo and sim.err_evo == ref.err_evo
+    got = sim.host_fields()
+    for k in ("Pr", "Vx", "Vy", "C"):
+        assert rel_l2(got[k], getattr(ref, k)) <= TOL, k
+        assert same_bits(got[k], getattr(ref, k)), k
+    assert same_bits(sim.dPrdtau_host(), ref.dPrdtau)

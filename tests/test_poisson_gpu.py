@@ -157,3 +157,35 @@ def test_poisson_division_forms(oracle, div):
                 assert same_bits(gdP, dP), (scale, zero_frac, pitched)
     finally:
         ctx.close()
+
+
+def test_poisson_full_size_grid(oracle):
+    """The benchmark grid (NavierStokes_Re6.jl at n = 16: 2559 x 4095, 23 strips x ~80 chunks, all
+    task shapes and the XCD-aware task numbering in play): 11 passes against the oracle, and the
+    size-independent property that the result does not depend on how the passes are grouped into
+    launches or how the grid is cut into tasks."""
+    import torch
+    from navierstokes_amd import _lib
+    p = ns_params("NavierStokes_Re6", n=16)
+    nx, ny = p.nx, p.ny
+    assert (nx, ny) == (2559, 4095)
+    rng = np.random.default_rng(2559)
+    Pr0, dP0, dv = rng_field(rng, nx, ny, 1e-2), rng_field(rng, nx - 2, ny - 2, 1e-2), rng_field(rng, nx, ny, 1e-2)
+    Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
+    oracle_iters(oracle, p, Pr, dP, dv, 11, 0)
+    ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        for k, rows, edge, xcd in [(0, 0, 0, 1), (0, 0, 0, 0), (3, 37, 50, 1), (8, 200, 100, 1), (1, 0, 0, 1)]:
+            ctx.set_option("poisson_k", k)
+            ctx.set_option("poisson_rows", rows)
+            ctx.set_option("poisson_edge_percent", edge)
+            ctx.set_option("poisson_xcd", xcd)
+            gPr, gdP = run_gpu(ctx, p, Pr0, dP0, dv, 11, 0, True)
+            assert same_bits(gPr, Pr), (k, rows, edge, xcd, np.argwhere(gPr != Pr)[:5])
+            assert same_bits(gdP, dP), (k, rows, edge, xcd, np.argwhere(gdP != dP)[:5])
+        ctx.set_option("poisson_k", 0)
+        ctx.set_option("poisson_rows", 0)
+        gPr, gdP = run_gpu(ctx, p, Pr0, dP0, dv, 11, 0, False)      # dense, odd leading dimension
+        assert same_bits(gPr, Pr) and same_bits(gdP, dP)
+    finally:
+        ctx.close()
