@@ -189,3 +189,24 @@ def test_poisson_full_size_grid(oracle):
         assert same_bits(gPr, Pr) and same_bits(gdP, dP)
     finally:
         ctx.close()
+
+
+def test_poisson_slab_windows_full_width(gpu, oracle):
+    """Slab windows of the benchmark grid (what each rank of a 2-GPU run computes between two
+    halo exchanges): 12 passes on the lower and the upper window equal the single-domain result
+    on all rows further than 12 from the windows' halo edges."""
+    p = ns_params("NavierStokes_Re6", n=16)
+    nx, nyg, count = p.nx, p.ny, 12
+    rng = np.random.default_rng(4095)
+    Pr0, dP0, dv = rng_field(rng, nx, nyg, 1e-2), rng_field(rng, nx - 2, nyg - 2, 1e-2), rng_field(rng, nx, nyg, 1e-2)
+    Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
+    oracle_iters(oracle, p, Pr, dP, dv, count, 0)
+    for lo, hi in [(0, 2112), (1984, nyg)]:
+        wPr, wdv = np.asfortranarray(Pr0[:, lo:hi]), np.asfortranarray(dv[:, lo:hi])
+        wdP = np.asfortranarray(dP0[:, lo:hi - 2])
+        gPr, gdP = run_gpu(gpu, p, wPr, wdP, wdv, count, 0, True, iy0=lo, nyg=nyg)
+        a = 0 if lo == 0 else count
+        b = (hi - lo) if hi == nyg else (hi - lo) - count
+        assert same_bits(gPr[:, a:b], Pr[:, lo + a:lo + b]), (lo, hi)
+        pa, pb = max(a, 1), min(b, hi - lo - 1)
+        assert same_bits(gdP[:, pa - 1:pb - 1], dP[:, lo + pa - 1:lo + pb - 1]), (lo, hi)
