@@ -140,6 +140,7 @@ extern "C" int nsk_bub_solve_pressure_rb(nsk_ctx *ctx, double *p, const double *
                                          const double *rt, double beta, double dx, double dy, int nx, int ny,
                                          int maxit, double maxError, int *sweeps_out, double *change_out) {
   NSK_CTX(ctx);
+  NSK_NONNULL(p, tmp1, tmp2, rt);
   NSK_REQUIRE(nx >= 2 && ny >= 2, "solve_pressure_rb: grid too small: nx=%d ny=%d", nx, ny);
   NSK_REQUIRE(maxit >= 1, "solve_pressure_rb: maxit=%d", maxit);
   const dim3 block(256), grid(nsk_cdiv((unsigned)(nx + 1) / 2 + 1, 256), (unsigned)ny);
@@ -154,6 +155,7 @@ extern "C" int nsk_bub_pt_pressure(nsk_ctx *ctx, double *p, double *dPdtau, cons
                                    const double *rt, double dtau, double damp, double dx, double dy, int nx,
                                    int ny, int maxit, double maxError, int *iters_out, double *change_out) {
   NSK_CTX(ctx);
+  NSK_NONNULL(p, dPdtau, tmp1, rt);
   NSK_REQUIRE(nx >= 2 && ny >= 2, "pt_pressure: grid too small: nx=%d ny=%d", nx, ny);
   NSK_REQUIRE(maxit >= 1, "pt_pressure: maxit=%d", maxit);
   const dim3 block(256), grid(nsk_cdiv((unsigned)nx, 256), (unsigned)ny);

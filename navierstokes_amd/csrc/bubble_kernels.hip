@@ -482,6 +482,7 @@ extern "C" int nsk_bub_set_density(nsk_ctx *ctx, double *r, double *m, double xc
                                    const double *x, const double *y, double rad, double rho2,
                                    double m2, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(r, x, y);
   NSK_BGRID_OK(nx, ny);
   k_set_density<<<grid2(nx + 2, ny + 2), block2(), 0, ctx->stream>>>(r, m, xc, yc, x, y, rad, rho2, m2, nx, ny);
   NSK_LAUNCH_CHECK();
@@ -491,6 +492,7 @@ extern "C" int nsk_bub_set_density(nsk_ctx *ctx, double *r, double *m, double xc
 extern "C" int nsk_bub_set_tangential(nsk_ctx *ctx, double *u, double *v, double usouth,
                                       double unorth, double vwest, double veast, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(u, v);
   NSK_BGRID_OK(nx, ny);
   const int n = (nx > ny ? nx : ny) + 1;
   k_set_tangential<<<nsk_cdiv(n, 256), 256, 0, ctx->stream>>>(u, v, usouth, unorth, vwest, veast, nx, ny);
@@ -502,6 +504,7 @@ extern "C" int nsk_bub_temp_vel(nsk_ctx *ctx, double *ut, double *vt, const doub
                                 const double *v, const double *r, double dt, double dx, double dy,
                                 double gx, double gy, double m0, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(u, v, r);
   NSK_BGRID_OK(nx, ny);
   k_temp_vel<<<grid2(nx + 1, ny + 1), block2(), 0, ctx->stream>>>(ut, vt, u, v, r, dt, dx, dy, gx, gy, m0, nx, ny);
   NSK_LAUNCH_CHECK();
@@ -513,6 +516,7 @@ extern "C" int nsk_bub_temp_vel_adv(nsk_ctx *ctx, double *ut, double *vt, const 
                                     double dy, const double *fx, const double *fy, double gx,
                                     double gy, double rro, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(ut, vt, u, v, r, fx, fy);
   NSK_BGRID_OK(nx, ny);
   k_temp_vel_adv<<<grid2(nx + 1, ny + 1), block2(), 0, ctx->stream>>>(ut, vt, u, v, r, dt, dx, dy, fx, fy, gx, gy, rro, nx, ny);
   NSK_LAUNCH_CHECK();
@@ -523,6 +527,7 @@ extern "C" int nsk_bub_temp_vel_diff(nsk_ctx *ctx, double *ut, double *vt, const
                                      const double *v, const double *r, double dt, double dx,
                                      double dy, const double *m, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(ut, vt, u, v, r, m);
   NSK_BGRID_OK(nx, ny);
   k_temp_vel_diff<<<grid2(nx + 1, ny + 1), block2(), 0, ctx->stream>>>(ut, vt, u, v, r, dt, dx, dy, m, nx, ny);
   NSK_LAUNCH_CHECK();
@@ -531,6 +536,7 @@ extern "C" int nsk_bub_temp_vel_diff(nsk_ctx *ctx, double *ut, double *vt, const
 
 extern "C" int nsk_bub_set_boundary(nsk_ctx *ctx, double *rt, const double *r, double lrg, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(rt, r);
   NSK_BGRID_OK(nx, ny);
   k_set_boundary<<<grid2(nx + 2, ny + 2), block2(), 0, ctx->stream>>>(rt, r, lrg, nx, ny);
   NSK_LAUNCH_CHECK();
@@ -541,6 +547,7 @@ extern "C" int nsk_bub_compute_sources(nsk_ctx *ctx, double *tmp1, double *tmp2,
                                        const double *ut, const double *vt, double dt, double dx,
                                        double dy, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(tmp1, tmp2, rt, ut, vt);
   NSK_BGRID_OK(nx, ny);
   k_compute_sources<<<grid2(nx + 2, ny + 2), block2(), 0, ctx->stream>>>(tmp1, tmp2, rt, ut, vt, dt, dx, dy, nx, ny);
   NSK_LAUNCH_CHECK();
@@ -552,6 +559,7 @@ extern "C" int nsk_bub_solve_pressure(nsk_ctx *ctx, double *p, const double *tmp
                                       double dy, int nx, int ny, int maxit, double maxError,
                                       int *sweeps_out, double *change_out) {
   NSK_CTX(ctx);
+  NSK_NONNULL(p, tmp1, tmp2, rt);
   NSK_BGRID_OK(nx, ny);
   NSK_REQUIRE(maxit >= 1, "solve_pressure: maxit=%d", maxit);
   return launch_sor(ctx, 0, p, tmp1, tmp2, rt, beta, dx, dy, nx, ny, maxit, maxError, sweeps_out, change_out);
@@ -561,6 +569,7 @@ extern "C" int nsk_bub_construct_den(nsk_ctx *ctx, double *r, const double *fx, 
                                      double beta, int maxit, double maxError, double dx, double dy,
                                      int nx, int ny, int *sweeps_out) {
   NSK_CTX(ctx);
+  NSK_NONNULL(r, fx, fy);
   NSK_BGRID_OK(nx, ny);
   NSK_REQUIRE(maxit >= 1, "construct_den: maxit=%d", maxit);
   return launch_sor(ctx, 1, r, fx, fy, nullptr, beta, dx, dy, nx, ny, maxit, maxError, sweeps_out, nullptr);
@@ -570,6 +579,7 @@ extern "C" int nsk_bub_correct_vel(nsk_ctx *ctx, double *u, double *v, const dou
                                    const double *vt, const double *p, const double *r, double dt,
                                    double dx, double dy, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(ut, vt, p, r);
   NSK_BGRID_OK(nx, ny);
   k_correct_vel<<<grid2(nx + 1, ny + 1), block2(), 0, ctx->stream>>>(u, v, ut, vt, p, r, dt, dx, dy, nx, ny);
   NSK_LAUNCH_CHECK();
@@ -580,6 +590,7 @@ extern "C" int nsk_bub_advect_density(nsk_ctx *ctx, double *r, const double *ro,
                                       const double *v, double dt, double dx, double dy, double m0,
                                       int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(r, ro, u, v);
   NSK_BGRID_OK(nx, ny);
   k_advect_density<<<grid2(nx + 2, ny + 2), block2(), 0, ctx->stream>>>(r, ro, u, v, dt, dx, dy, m0, nx, ny);
   NSK_LAUNCH_CHECK();
@@ -589,6 +600,7 @@ extern "C" int nsk_bub_advect_density(nsk_ctx *ctx, double *r, const double *ro,
 extern "C" int nsk_bub_velocity(nsk_ctx *ctx, double *uu, double *vv, const double *u,
                                 const double *v, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(uu, vv, u, v);
   NSK_BGRID_OK(nx, ny);
   k_velocity<<<grid2(nx + 1, ny + 1), block2(), 0, ctx->stream>>>(uu, vv, u, v, nx, ny);
   NSK_LAUNCH_CHECK();
@@ -598,6 +610,7 @@ extern "C" int nsk_bub_velocity(nsk_ctx *ctx, double *uu, double *vv, const doub
 extern "C" int nsk_bub_update_visco(nsk_ctx *ctx, const double *r, double *m, double m1, double m2,
                                     double rho1, double rho2, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(r, m);
   NSK_BGRID_OK(nx, ny);
   k_update_visco<<<grid2(nx + 2, ny + 2), block2(), 0, ctx->stream>>>(r, m, m1, m2, rho1, rho2, nx, ny);
   NSK_LAUNCH_CHECK();
@@ -606,6 +619,7 @@ extern "C" int nsk_bub_update_visco(nsk_ctx *ctx, const double *r, double *m, do
 
 extern "C" int nsk_bub_average(nsk_ctx *ctx, double *a, const double *b, size_t count) {
   NSK_CTX(ctx);
+  NSK_NONNULL(a, b);
   if (count) {
     k_average<<<(unsigned)((count + 255) / 256), 256, 0, ctx->stream>>>(a, b, count);
     NSK_LAUNCH_CHECK();
@@ -617,6 +631,7 @@ extern "C" int nsk_bub_surface_tension(nsk_ctx *ctx, double *fx, double *fy, dou
                                        const double *xf, const double *yf, double sigma, double dx,
                                        double dy, int nx, int ny, int Nf) {
   NSK_CTX(ctx);
+  NSK_NONNULL(fx, fy, tx, ty, xf, yf);
   NSK_BGRID_OK(nx, ny);
   NSK_REQUIRE(Nf >= 1, "surface_tension: Nf=%d", Nf);
   k_front_tangents<<<nsk_cdiv(Nf + 2, 256), 256, 0, ctx->stream>>>(tx, ty, xf, yf, Nf);
@@ -630,6 +645,7 @@ extern "C" int nsk_bub_distribute(nsk_ctx *ctx, double *fx, double *fy, const do
                                   const double *yf, double rho1, double rho2, double dx, double dy,
                                   int nx, int ny, int Nf) {
   NSK_CTX(ctx);
+  NSK_NONNULL(fx, fy, xf, yf);
   NSK_BGRID_OK(nx, ny);
   NSK_REQUIRE(Nf >= 1, "distribute: Nf=%d", Nf);
   k_spread<1><<<grid2(nx + 2, ny + 2), block2(), 0, ctx->stream>>>(fx, fy, xf, yf, nullptr, nullptr, rho1, rho2, dx, dy, nx, ny, Nf);
@@ -642,6 +658,7 @@ extern "C" int nsk_bub_advect_move_front(nsk_ctx *ctx, double *uf, double *vf, d
                                          double dt, double Lx, double Ly, int nx, int ny, int Nf,
                                          int *out_of_bounds) {
   NSK_CTX(ctx);
+  NSK_NONNULL(uf, vf, xf, yf, u, v);
   NSK_BGRID_OK(nx, ny);
   NSK_REQUIRE(Nf >= 1, "advect_move_front: Nf=%d", Nf);
   int *d_cnt = reinterpret_cast<int *>(ctx->red_dev + 4);
@@ -663,6 +680,7 @@ extern "C" int nsk_bub_regrid_front(nsk_ctx *ctx, double *xf, double *yf, double
                                     double *yscratch, double dx, double dy, int Nf, int cap,
                                     int *Nf_out) {
   NSK_CTX(ctx);
+  NSK_NONNULL(xf, yf);
   NSK_REQUIRE(Nf_out != nullptr && Nf >= 1 && cap >= Nf + 2, "regrid_front: bad arguments (Nf=%d cap=%d)", Nf, cap);
   int *d_nf = reinterpret_cast<int *>(ctx->red_dev + 5);
   *reinterpret_cast<int *>(ctx->red_host + 5) = Nf;

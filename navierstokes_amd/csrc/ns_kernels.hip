@@ -280,6 +280,7 @@ extern "C" int nsk_update_tau(nsk_ctx *ctx, double *txx, double *tyy, double *tx
                               const double *Vx, const double *Vy, double mu, double dx, double dy,
                               int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(txx, tyy, txy, Vx, Vy);
   NSK_GRID_OK(nx, ny);
   k_update_tau<<<grid2(nx, ny), block2(), 0, ctx->stream>>>(txx, tyy, txy, Vx, Vy, mu, dx, dy, nx, ny);
   NSK_LAUNCH_CHECK();
@@ -290,6 +291,7 @@ extern "C" int nsk_predict_V(nsk_ctx *ctx, double *Vx, double *Vy, const double 
                              const double *tyy, const double *txy, double rho, double g, double dt,
                              double dx, double dy, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(Vx, Vy, txx, tyy, txy);
   NSK_GRID_OK(nx, ny);
   k_predict_V<<<grid2(nx - 1, ny - 1), block2(), 0, ctx->stream>>>(Vx, Vy, txx, tyy, txy, dt / rho,
                                                                  rho * g, dx, dy, nx, ny);
@@ -301,6 +303,7 @@ extern "C" int nsk_set_sphere(nsk_ctx *ctx, double *C, double *Vx, double *Vy, d
                               double ox, double oy, double sinb, double cosb, double lx, double ly,
                               double dx, double dy, int nx, int ny, int iy0) {
   NSK_CTX(ctx);
+  NSK_NONNULL(C, Vx, Vy);
   NSK_GRID_OK(nx, ny);
   k_set_sphere<<<grid2(nx + 1, ny + 1), block2(), 0, ctx->stream>>>(C, Vx, Vy, a2, b2, ox, oy, sinb,
                                                                   cosb, lx, ly, dx, dy, nx, ny, iy0);
@@ -321,6 +324,7 @@ int nsk_i_update_divV(nsk_ctx *ctx, double *divV, int ld, const double *Vx, cons
 extern "C" int nsk_update_divV(nsk_ctx *ctx, double *divV, const double *Vx, const double *Vy,
                                double dx, double dy, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(divV, Vx, Vy);
   NSK_GRID_OK(nx, ny);
   return nsk_i_update_divV(ctx, divV, nx, Vx, Vy, dx, dy, nx, ny);
 }
@@ -329,6 +333,7 @@ extern "C" int nsk_update_dPrdtau(nsk_ctx *ctx, const double *Pr, double *dPrdta
                                   const double *divV, double rho, double dt, double dtau,
                                   double damp, double dx, double dy, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(Pr, dPrdtau, divV);
   NSK_GRID_OK(nx, ny);
   k_update_dPrdtau<<<grid2(nx - 2, ny - 2), block2(), 0, ctx->stream>>>(
       Pr, dPrdtau, divV, rho / dt, dtau, 1.0 - damp, dx, dy, nx, ny);
@@ -339,6 +344,7 @@ extern "C" int nsk_update_dPrdtau(nsk_ctx *ctx, const double *Pr, double *dPrdta
 extern "C" int nsk_update_Pr(nsk_ctx *ctx, double *Pr, const double *dPrdtau, double dtau, int nx,
                              int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(Pr, dPrdtau);
   NSK_GRID_OK(nx, ny);
   k_update_Pr<<<grid2(nx - 2, ny - 2), block2(), 0, ctx->stream>>>(Pr, dPrdtau, dtau, nx, ny);
   NSK_LAUNCH_CHECK();
@@ -358,6 +364,7 @@ static int bc_x_rows(int n1, int n2g, int n2w, int iy0, int full_rows) {
 extern "C" int nsk_set_bc_Pr(nsk_ctx *ctx, double *Pr, double val, int nx, int ny, int full_rows,
                              int iy0, int nyg) {
   NSK_CTX(ctx);
+  NSK_NONNULL(Pr);
   NSK_GRID_OK(nx, ny);
   NSK_REQUIRE(iy0 >= 0 && iy0 + ny <= nyg, "set_bc_Pr: window [%d,%d] outside 1..%d", iy0 + 1,
               iy0 + ny, nyg);
@@ -377,6 +384,7 @@ extern "C" int nsk_set_bc_Pr(nsk_ctx *ctx, double *Pr, double val, int nx, int n
 extern "C" int nsk_compute_res(nsk_ctx *ctx, double *Rp, const double *Pr, const double *divV,
                                double rho, double dt, double dx, double dy, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(Rp, Pr, divV);
   NSK_GRID_OK(nx, ny);
   k_compute_res<<<grid2(nx - 2, ny - 2), block2(), 0, ctx->stream>>>(Rp, Pr, divV, rho / dt, dx, dy,
                                                                    nx, ny);
@@ -405,6 +413,7 @@ int nsk_i_correct_V(nsk_ctx *ctx, double *Vx, double *Vy, const double *Pr, int 
 extern "C" int nsk_correct_V(nsk_ctx *ctx, double *Vx, double *Vy, const double *Pr, double dt,
                              double rho, double dx, double dy, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(Vx, Vy, Pr);
   NSK_GRID_OK(nx, ny);
   return nsk_i_correct_V(ctx, Vx, Vy, Pr, nx, dt, rho, dx, dy, nx, ny);
 }
@@ -412,6 +421,7 @@ extern "C" int nsk_correct_V(nsk_ctx *ctx, double *Vx, double *Vy, const double 
 extern "C" int nsk_set_bc_Vel(nsk_ctx *ctx, double *Vx, double *Vy, const double *Vprof, int nx,
                               int ny, int full_rows, int iy0, int nyg) {
   NSK_CTX(ctx);
+  NSK_NONNULL(Vx, Vy, Vprof);
   NSK_GRID_OK(nx, ny);
   NSK_REQUIRE(iy0 >= 0 && iy0 + ny <= nyg, "set_bc_Vel: window [%d,%d] outside 1..%d", iy0 + 1,
               iy0 + ny, nyg);
@@ -438,6 +448,7 @@ extern "C" int nsk_advect(nsk_ctx *ctx, double *Vx, const double *Vx_o, double *
                           const double *Vy_o, double *C, const double *C_o, double dt, double dx,
                           double dy, int nx, int ny, int iy0, int nyg) {
   NSK_CTX(ctx);
+  NSK_NONNULL(Vx, Vx_o, Vy, Vy_o, C, C_o);
   NSK_GRID_OK(nx, ny);
   NSK_REQUIRE(iy0 >= 0 && iy0 + ny <= nyg, "advect: window [%d,%d] outside 1..%d", iy0 + 1,
               iy0 + ny, nyg);
@@ -450,6 +461,7 @@ extern "C" int nsk_advect(nsk_ctx *ctx, double *Vx, const double *Vx_o, double *
 extern "C" int nsk_update_divV_ld(nsk_ctx *ctx, double *divV, int ld, const double *Vx,
                                   const double *Vy, double dx, double dy, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(divV, Vx, Vy);
   NSK_GRID_OK(nx, ny);
   NSK_REQUIRE(ld >= nx, "update_divV: ld=%d smaller than nx=%d", ld, nx);
   return nsk_i_update_divV(ctx, divV, ld, Vx, Vy, dx, dy, nx, ny);
@@ -458,6 +470,7 @@ extern "C" int nsk_update_divV_ld(nsk_ctx *ctx, double *divV, int ld, const doub
 extern "C" int nsk_correct_V_ld(nsk_ctx *ctx, double *Vx, double *Vy, const double *Pr, int ld,
                                 double dt, double rho, double dx, double dy, int nx, int ny) {
   NSK_CTX(ctx);
+  NSK_NONNULL(Vx, Vy, Pr);
   NSK_GRID_OK(nx, ny);
   NSK_REQUIRE(ld >= nx, "correct_V: ld=%d smaller than nx=%d", ld, nx);
   return nsk_i_correct_V(ctx, Vx, Vy, Pr, ld, dt, rho, dx, dy, nx, ny);

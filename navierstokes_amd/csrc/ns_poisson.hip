@@ -144,6 +144,7 @@ int ensure_pingpong(nsk_ctx *ctx, size_t elems) {
 extern "C" int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double *divV,
                                     const nsk_ns_params *p, int count) {
   NSK_CTX(ctx);
+  NSK_NONNULL(Pr, dPrdtau, divV);
   if (int rc = check_params(p)) return rc;
   NSK_REQUIRE(count >= 0, "negative pass count %d", count);
   if (count == 0) return 0;
@@ -216,6 +217,7 @@ extern "C" int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, c
 extern "C" int nsk_ns_residual(nsk_ctx *ctx, double *Rp, const double *Pr, const double *divV,
                                const nsk_ns_params *p, int own_lo, int own_hi, double *maxabs_out) {
   NSK_CTX(ctx);
+  NSK_NONNULL(Pr, divV);  // Rp may be null: only the maximum is wanted
   if (int rc = check_params(p)) return rc;
   NSK_REQUIRE(maxabs_out != nullptr, "nsk_ns_residual: maxabs_out is null");
   const int nx = p->nx, ny = p->ny;
@@ -231,6 +233,7 @@ extern "C" int nsk_ns_poisson(nsk_ctx *ctx, double *Pr, double *dPrdtau, double 
                               const double *divV, const nsk_ns_params *p, int *iters_out,
                               double *err_hist, int *iter_hist, int hist_cap, int *nhist_out) {
   NSK_CTX(ctx);
+  NSK_NONNULL(Pr, dPrdtau, Rp, divV);
   if (int rc = check_params(p)) return rc;
   NSK_REQUIRE(p->iy0 == 0 && p->ny == p->nyg, "nsk_ns_poisson works on a whole domain");
   const int niter = p->niter, nchk = p->nchk;

@@ -16,6 +16,8 @@ extern "C" int nsk_ns_step(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_par
                            int *nhist_out) {
   NSK_CTX(ctx);
   NSK_REQUIRE(s != nullptr && p != nullptr, "nsk_ns_step: null argument");
+  NSK_NONNULL(s->Pr, s->dPrdtau, s->C, s->C_o, s->txx, s->tyy, s->txy, s->Vx, s->Vy, s->Vx_o, s->Vy_o, s->divV,
+              s->Rp, s->Vprof);
   NSK_REQUIRE(p->iy0 == 0 && p->ny == p->nyg, "nsk_ns_step works on a whole domain");
   const int nx = p->nx, ny = p->ny;
   const int ld = p->ld_pr ? p->ld_pr : nx;

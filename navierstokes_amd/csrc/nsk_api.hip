@@ -158,6 +158,8 @@ extern "C" int nsk_free(nsk_ctx *ctx, double *dev) {
 
 extern "C" int nsk_upload(nsk_ctx *ctx, double *dev, const double *host, size_t count) {
   NSK_CTX(ctx);
+  if (count == 0) return 0;
+  NSK_NONNULL(dev, host);
   NSK_HIP(hipMemcpyAsync(dev, host, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   NSK_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
@@ -165,6 +167,8 @@ extern "C" int nsk_upload(nsk_ctx *ctx, double *dev, const double *host, size_t 
 
 extern "C" int nsk_download(nsk_ctx *ctx, double *host, const double *dev, size_t count) {
   NSK_CTX(ctx);
+  if (count == 0) return 0;
+  NSK_NONNULL(host, dev);
   NSK_HIP(hipMemcpyAsync(host, dev, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   NSK_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
@@ -172,6 +176,8 @@ extern "C" int nsk_download(nsk_ctx *ctx, double *host, const double *dev, size_
 
 extern "C" int nsk_copy(nsk_ctx *ctx, double *dst, const double *src, size_t count) {
   NSK_CTX(ctx);
+  if (count == 0) return 0;
+  NSK_NONNULL(dst, src);
   NSK_HIP(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   return 0;
 }

@@ -58,6 +58,15 @@ void nsk_set_error(const char *fmt, ...);
   NSK_REQUIRE((ctx) != nullptr, "null context");                               \
   NSK_HIP(hipSetDevice((ctx)->device))
 
+// A null device array would be dereferenced on the GPU (a memory fault there can take the
+// whole device down), so every entry point rejects it on the host.
+template <class... T>
+static inline bool nsk_all_nonnull(const T *...p) {
+  return (... && (p != nullptr));
+}
+#define NSK_NONNULL(...) \
+  NSK_REQUIRE(nsk_all_nonnull(__VA_ARGS__), "%s: null array argument", __func__)
+
 #define NSK_LAUNCH_CHECK() NSK_HIP(hipGetLastError())
 
 // Column-major element: A[ix,iy], 1-based like the reference's kernels.
