@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnsk.so")
+LIB_PATH = os.environ.get("NSK_LIB") or os.path.join(_HERE, "libnsk.so")   # NSK_LIB: another build of the same ABI
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
