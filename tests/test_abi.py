@@ -69,3 +69,16 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("the oracle", "").replace("oracle's", "") or f == "dist.py", (dirpath, f)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/nsk.h is the boundary for foreign-language callers: it must compile as C99 and
+    as C++ with nothing but the standard headers."""
+    import subprocess
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "nsk.h")
+    src = tmp_path / "h.c"
+    src.write_text(f'#include "{hdr}"\nint main(void) {{ nsk_ns_params p; p.nx = 3; return p.nx - 3; }}\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", str(src)], check=True)
+    cpp = tmp_path / "h.cpp"
+    cpp.write_text(f'#include "{hdr}"\nint main() {{ nsk_ns_state s{{}}; return s.Pr != nullptr; }}\n')
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", str(cpp)], check=True)
