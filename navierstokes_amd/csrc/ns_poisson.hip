@@ -40,26 +40,25 @@ namespace {
 using namespace nsk_poisson;
 
 namespace nsk_poisson {
-#define NSK_DECL(K) extern template int launch_k<K>(nsk_ctx *, PoissonArgs &, bool, int, int, int);
+#define NSK_DECL(K) extern template int launch_k<K>(nsk_ctx *, PoissonArgs &, bool, int, const TaskPlan &);
 NSK_DECL(1) NSK_DECL(2) NSK_DECL(3) NSK_DECL(4) NSK_DECL(5) NSK_DECL(6) NSK_DECL(7) NSK_DECL(8)
 #undef NSK_DECL
 }  // namespace nsk_poisson
 
 namespace {
 
-int launch_poisson(nsk_ctx *ctx, PoissonArgs &A, int K, bool aligned, int div, int rpc) {
-  const int ep = ctx->poisson_edge_percent;
-  switch (K) {
-    case 1: return launch_k<1>(ctx, A, aligned, div, rpc, ep);
-    case 2: return launch_k<2>(ctx, A, aligned, div, rpc, ep);
-    case 3: return launch_k<3>(ctx, A, aligned, div, rpc, ep);
-    case 4: return launch_k<4>(ctx, A, aligned, div, rpc, ep);
-    case 5: return launch_k<5>(ctx, A, aligned, div, rpc, ep);
-    case 6: return launch_k<6>(ctx, A, aligned, div, rpc, ep);
-    case 7: return launch_k<7>(ctx, A, aligned, div, rpc, ep);
-    case 8: return launch_k<8>(ctx, A, aligned, div, rpc, ep);
+int launch_poisson(nsk_ctx *ctx, PoissonArgs &A, bool aligned, int div, const TaskPlan &plan) {
+  switch (plan.K) {
+    case 1: return launch_k<1>(ctx, A, aligned, div, plan);
+    case 2: return launch_k<2>(ctx, A, aligned, div, plan);
+    case 3: return launch_k<3>(ctx, A, aligned, div, plan);
+    case 4: return launch_k<4>(ctx, A, aligned, div, plan);
+    case 5: return launch_k<5>(ctx, A, aligned, div, plan);
+    case 6: return launch_k<6>(ctx, A, aligned, div, plan);
+    case 7: return launch_k<7>(ctx, A, aligned, div, plan);
+    case 8: return launch_k<8>(ctx, A, aligned, div, plan);
   }
-  nsk_set_error("poisson: unsupported passes per launch %d", K);
+  nsk_set_error("passes per launch %d outside 1..8", plan.K);
   return 2;
 }
 
@@ -186,9 +185,14 @@ extern "C" int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, c
   }
   if (ctx->poisson_div >= 0) div = ctx->poisson_div == 3 ? DIV_FMA3 : ctx->poisson_div == 4 ? DIV_FMA4 : DIV_IEEE;
 
-  int kmax = ctx->poisson_k > 0 ? ctx->poisson_k : NSK_DEFAULT_POISSON_K;
-  if (kmax > 8) kmax = 8;
-  const int rpc = ctx->poisson_rows;
+  // Passes per launch and task shape: forced by the options, otherwise the cheapest by the
+  // planner's estimate for this grid.
+  const int ep = ctx->poisson_edge_percent;
+  const TaskPlan top = choose_plan(nx, ny, ctx->num_simds, ctx->poisson_k, count < 8 ? count : 8,
+                                   ctx->poisson_rows, ep);
+  const int kmax = top.K;
+  ctx->last_plan_k = top.K;
+  ctx->last_plan_rows = top.rows;
 
   // Split `count` into launches of at most kmax passes; make the number of
   // launches even when possible so the result lands in the caller's arrays.
@@ -202,7 +206,8 @@ extern "C" int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, c
     A.dp_src = src_dp;
     A.pr_dst = dst_pr;
     A.dp_dst = dst_dp;
-    if (int rc = launch_poisson(ctx, A, k, aligned, div, rpc)) return rc;
+    const TaskPlan plan = k == top.K ? top : choose_plan(nx, ny, ctx->num_simds, k, k, ctx->poisson_rows, ep);
+    if (int rc = launch_poisson(ctx, A, aligned, div, plan)) return rc;
     left -= k;
     double *t = src_pr; src_pr = dst_pr; dst_pr = t;
     t = src_dp; src_dp = dst_dp; dst_dp = t;

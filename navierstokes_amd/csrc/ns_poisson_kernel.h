@@ -628,43 +628,95 @@ __global__ void __launch_bounds__(64) NSK_WAVES_ATTR k_poisson(PoissonArgs A) {
 #endif
 }
 
-template <int K>
-int launch_k(nsk_ctx *ctx, PoissonArgs &A, bool aligned, int div, int rows_per_chunk_hint, int edge_percent) {
-  constexpr int HK = (K + 1) & ~1;
-  constexpr int WOUT = 128 - 2 * HK;
-  A.nstrips = (A.nx - 1 + WOUT - 1) / WOUT;  // columns 0..nx-2; nx-1 rides with nx-2
-  // One wavefront per task, NSK_WAVES of them resident per SIMD: the launch is fastest when all
-  // tasks are resident at once (one round) and equally long.  The two edge strips carry the
-  // boundary-column work on top, so their chunks are shorter (edge_percent of the others').
-  // Automatic choice: the smallest chunk height whose task count still fits one round.
-  const int slots = ctx->num_simds * NSK_WAVES;
-  const int ep = edge_percent > 0 ? edge_percent : 75;
-  const int nint = A.nstrips > 2 ? A.nstrips - 2 : 0, nedge = A.nstrips >= 2 ? 2 : 1;
-  const int min_rows = 2 * K > 2 ? 2 * K : 2;
-  auto edge_rows = [&](int rpc) {
-    int rpe = (int)((long)rpc * ep / 100);
-    if (rpe < min_rows) rpe = min_rows;
-    return rpe > rpc ? rpc : rpe;
-  };
-  auto task_count = [&](int rpc) {
-    const int rpe = edge_rows(rpc);
-    return (long)nint * ((A.ny + rpc - 1) / rpc) + (long)nedge * ((A.ny + rpe - 1) / rpe);
-  };
-  int rpc = rows_per_chunk_hint;
-  if (rpc <= 0) {
-    rpc = (int)(((long)A.ny * A.nstrips + slots - 1) / slots);
-    if (rpc < min_rows) rpc = min_rows;
-    while (rpc < A.ny && task_count(rpc) > slots) rpc++;
+// ---- host side: how a launch is cut into tasks -------------------------------------------------
+
+// Geometry of one launch: strips of WOUT output columns x chunks of rows.  The first and the last
+// strip carry the boundary-column work on top, so their chunks are shorter.
+struct TaskPlan {
+  int K, nstrips, rows, rows_edge, nchunks, nchunks_edge;
+  long tasks;
+  double est_us_per_pass;
+};
+
+inline TaskPlan plan_tasks(int K, int nx, int ny, int rows, int edge_percent) {
+  TaskPlan t;
+  const int HK = (K + 1) & ~1, WOUT = 128 - 2 * HK;
+  t.K = K;
+  t.nstrips = (nx - 1 + WOUT - 1) / WOUT;  // columns 0..nx-2; nx-1 rides with nx-2
+  if (rows < 2) rows = 2;
+  if (rows > ny) rows = ny;
+  int re = (int)((long)rows * (edge_percent > 0 ? edge_percent : 75) / 100);
+  if (re < 2) re = 2;
+  if (re > rows) re = rows;
+  t.rows = rows;
+  t.rows_edge = re;
+  t.nchunks = (ny + rows - 1) / rows;
+  t.nchunks_edge = (ny + re - 1) / re;
+  const int nint = t.nstrips > 2 ? t.nstrips - 2 : 0, nedge = t.nstrips >= 2 ? 2 : 1;
+  t.tasks = (long)nint * t.nchunks + (long)nedge * t.nchunks_edge;
+  t.est_us_per_pass = 0.0;
+  return t;
+}
+
+// Estimated time of a launch with this plan, per pass.  One wavefront per task, at most
+// NSK_WAVES resident per SIMD; a task streams rows + 3K - 1 row steps of K passes each.  Measured
+// on MI355X: 0.22 us per row and pass with one wavefront on a SIMD, 0.31 us with two; the memory
+// side moves the three inputs (with their halo re-reads) and the two outputs at about 4.8 TB/s;
+// about 3 us per launch on top.
+inline double plan_cost(const TaskPlan &t, int nx, int ny, int num_simds) {
+  const int K = t.K, HK = (K + 1) & ~1, WOUT = 128 - 2 * HK;
+  const long slots = (long)num_simds * NSK_WAVES;
+  const double rounds = (double)((t.tasks + slots - 1) / slots);
+  const double per_row = t.tasks > num_simds ? 0.31 : 0.22;
+  const double alu = rounds * (t.rows + 3 * K - 1) * K * per_row;
+  const double mem = 8.0 * nx * ny * (3.0 * (1.0 + 2.0 * K / t.rows) * (128.0 / WOUT) + 2.0) / 4.8e6;
+  return ((alu > mem ? alu : mem) + 3.0) / K;
+}
+
+// Passes per launch and chunk height.  k_forced / rows_forced > 0 pin the respective choice;
+// k_limit caps the automatic K (no more passes than are asked for).
+inline TaskPlan choose_plan(int nx, int ny, int num_simds, int k_forced, int k_limit, int rows_forced,
+                            int edge_percent) {
+  // automatic K stops at 5: beyond that the kernel no longer fits two wavefronts per SIMD
+  int klo = 1, khi = 5;
+  if (k_forced > 0) klo = khi = k_forced;
+  if (khi > k_limit) khi = k_limit;
+  if (klo > khi) klo = khi;
+  const long slots = (long)num_simds * NSK_WAVES;
+  TaskPlan best{};
+  bool have = false;
+  for (int K = klo; K <= khi; K++) {
+    int rlo = rows_forced, rhi = rows_forced;
+    if (rows_forced <= 0) {
+      // from the smallest height that fits one round to the one that leaves one task per SIMD
+      rlo = 2;
+      while (rlo < ny && plan_tasks(K, nx, ny, rlo, edge_percent).tasks > slots) rlo++;
+      rhi = rlo;
+      while (rhi < ny && plan_tasks(K, nx, ny, rhi, edge_percent).tasks > num_simds) rhi++;
+      if (rhi > rlo + 256) rhi = rlo + 256;
+    }
+    for (int r = rlo; r <= rhi; r++) {
+      TaskPlan t = plan_tasks(K, nx, ny, r, edge_percent);
+      t.est_us_per_pass = plan_cost(t, nx, ny, num_simds);
+      if (!have || t.est_us_per_pass < best.est_us_per_pass) {
+        best = t;
+        have = true;
+      }
+    }
   }
-  if (rpc < 2) rpc = 2;
-  const int rpe = edge_rows(rpc);
-  A.rows_per_chunk = rpc;
-  A.nchunks = (A.ny + rpc - 1) / rpc;
-  A.rows_per_chunk_edge = rpe;
-  A.nchunks_edge = (A.ny + rpe - 1) / rpe;
-  A.n_interior_tasks = nint * A.nchunks;
+  return best;
+}
+
+template <int K>
+int launch_k(nsk_ctx *ctx, PoissonArgs &A, bool aligned, int div, const TaskPlan &plan) {
+  A.nstrips = plan.nstrips;
+  A.rows_per_chunk = plan.rows;
+  A.nchunks = plan.nchunks;
+  A.rows_per_chunk_edge = plan.rows_edge;
+  A.nchunks_edge = plan.nchunks_edge;
+  A.n_interior_tasks = (plan.nstrips > 2 ? plan.nstrips - 2 : 0) * plan.nchunks;
   A.xcd_bands = ctx->poisson_xcd;
-  const unsigned tasks = (unsigned)task_count(rpc);
+  const unsigned tasks = (unsigned)plan.tasks;
 #define NSK_LAUNCH(AL, DV) k_poisson<K, AL, DV><<<tasks, 64, 0, ctx->stream>>>(A)
   if (aligned) {
     if (div == DIV_FMA3) NSK_LAUNCH(true, DIV_FMA3);
@@ -679,6 +731,5 @@ int launch_k(nsk_ctx *ctx, PoissonArgs &A, bool aligned, int div, int rows_per_c
   NSK_LAUNCH_CHECK();
   return 0;
 }
-
 
 }  // namespace nsk_poisson

@@ -41,8 +41,14 @@ extern "C" int nsk_create(int device, nsk_ctx **out) {
     nsk_destroy(c);
     return 1;
   }
-  if (const char *k = getenv("NSK_POISSON_K")) c->poisson_k = atoi(k);
-  if (const char *r = getenv("NSK_POISSON_ROWS")) c->poisson_rows = atoi(r);
+  if (const char *k = getenv("NSK_POISSON_K")) {
+    const int v = atoi(k);
+    if (v >= 0 && v <= 8) c->poisson_k = v;
+  }
+  if (const char *r = getenv("NSK_POISSON_ROWS")) {
+    const int v = atoi(r);
+    if (v >= 0) c->poisson_rows = v;
+  }
   *out = c;
   return 0;
 }
@@ -110,11 +116,16 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
 extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   NSK_REQUIRE(ctx != nullptr && name != nullptr && value != nullptr, "nsk_get_option: null argument");
   if (!strcmp(name, "poisson_k")) {
-    *value = ctx->poisson_k > 0 ? ctx->poisson_k : NSK_DEFAULT_POISSON_K;
+    // forced value, else what the planner chose in the last fused Poisson call (5 before any)
+    *value = ctx->poisson_k > 0 ? ctx->poisson_k : (ctx->last_plan_k > 0 ? ctx->last_plan_k : 5);
     return 0;
   }
   if (!strcmp(name, "poisson_rows")) {
     *value = ctx->poisson_rows;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_rows_used")) {
+    *value = ctx->last_plan_rows;
     return 0;
   }
   if (!strcmp(name, "poisson_xcd")) {

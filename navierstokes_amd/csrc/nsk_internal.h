@@ -9,7 +9,6 @@
 
 #include "../../include/nsk.h"
 
-#define NSK_DEFAULT_POISSON_K 5
 
 struct nsk_ctx {
   int device = 0;
@@ -27,7 +26,8 @@ struct nsk_ctx {
   // Per-iteration max|old-new| history of the batched iterative solvers (device + pinned host).
   unsigned long long *hist_dev = nullptr, *hist_host = nullptr;
   size_t hist_cap = 0;
-  int poisson_k = 0;     // passes per launch, 0 = NSK_DEFAULT_POISSON_K (NSK_POISSON_K / nsk_set_option)
+  int poisson_k = 0;     // passes per launch, 0 = chosen per grid (NSK_POISSON_K / nsk_set_option)
+  int last_plan_k = 0, last_plan_rows = 0;  // what the last fused Poisson call used (nsk_get_option)
   int poisson_div = -1;  // -1 = automatic; 0 / 3 / 4 force a division form (testing)
   int poisson_edge_percent = 0;  // rows per task of the edge strips in % of poisson_rows, 0 = default
   int poisson_xcd = 1;   // XCD-aware task numbering of the Poisson kernel (0 = plain)
