@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scale", dest="n", type=int, default=16, help="runme(n=...): nx=160n-1, ny=256n-1 per GPU")
-    ap.add_argument("--halo", type=int, default=64, help="halo rows = passes between exchanges (N>1)")
+    ap.add_argument("--halo", type=int, default=60, help="halo rows = passes between exchanges (N>1)")
     ap.add_argument("--passes", type=int, default=0, help="passes per step (default nchk)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
