@@ -64,6 +64,7 @@ extern "C" int nsk_destroy(nsk_ctx *c) {
   if (c->red_host) (void)hipHostFree(c->red_host);
   if (c->pp_pr) (void)hipFree(c->pp_pr);
   if (c->pp_dp) (void)hipFree(c->pp_dp);
+  if (c->iter_pp) (void)hipFree(c->iter_pp);
   if (c->hist_dev) (void)hipFree(c->hist_dev);
   if (c->hist_host) (void)hipHostFree(c->hist_host);
   delete c;

@@ -26,6 +26,8 @@ struct nsk_ctx {
   // Per-iteration max|old-new| history of the batched iterative solvers (device + pinned host).
   unsigned long long *hist_dev = nullptr, *hist_host = nullptr;
   size_t hist_cap = 0;
+  double *iter_pp = nullptr;  // ping-pong partner of p for those solvers
+  size_t iter_pp_elems = 0;
   int poisson_k = 0;     // passes per launch, 0 = chosen per grid (NSK_POISSON_K / nsk_set_option)
   int last_plan_k = 0, last_plan_rows = 0;  // what the last fused Poisson call used (nsk_get_option)
   int poisson_div = -1;  // -1 = automatic; 0 / 3 / 4 force a division form (testing)
