@@ -80,17 +80,20 @@ __global__ void __launch_bounds__(256) k_residual_max(double *__restrict__ Rp,
                                                       int ny, int own_lo, int own_hi,
                                                       unsigned long long *__restrict__ out) {
   // thread -> interior cell (ix,iy) of dPrdτ/Rp indexing (1-based, nx-2 x ny-2)
+  // (a workgroup walks down the rows in steps of 4*gridDim.y: few workgroups, hence few atomics
+  // on the one result word, which would otherwise cost more than the pass over the data)
   const int ix = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
-  const int iy = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
   unsigned long long m = 0;
-  if (ix <= nx - 2 && iy <= ny - 2) {
+  for (int iy = blockIdx.y * 4 + (threadIdx.x >> 6) + 1; ix <= nx - 2 && iy <= ny - 2; iy += 4 * gridDim.y) {
     double c = A2(Pr, ld, ix + 1, iy + 1);
     double d2x = (A2(Pr, ld, ix + 2, iy + 1) - c) - (c - A2(Pr, ld, ix, iy + 1));
     double d2y = (A2(Pr, ld, ix + 1, iy + 2) - c) - (c - A2(Pr, ld, ix + 1, iy));
     double res = d2x / dx / dx + d2y / dy / dy - rho_dt * A2(divV, ld, ix + 1, iy + 1);
     if (Rp) A2(Rp, nx - 2, ix, iy) = res;
-    if (iy + 1 >= own_lo && iy + 1 <= own_hi)
-      m = (unsigned long long)__double_as_longlong(fabs(res));
+    if (iy + 1 >= own_lo && iy + 1 <= own_hi) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(res));
+      m = b > m ? b : m;
+    }
   }
   for (int off = 32; off > 0; off >>= 1) {
     unsigned long long o = __shfl_xor(m, off, 64);
@@ -227,7 +230,8 @@ extern "C" int nsk_ns_residual(nsk_ctx *ctx, double *Rp, const double *Pr, const
   NSK_REQUIRE(maxabs_out != nullptr, "nsk_ns_residual: maxabs_out is null");
   const int nx = p->nx, ny = p->ny;
   NSK_HIP(hipMemsetAsync(ctx->red_dev, 0, sizeof(unsigned long long), ctx->stream));
-  dim3 grid(nsk_cdiv(nx - 2, 64), nsk_cdiv(ny - 2, 4));
+  const unsigned gy = nsk_cdiv(ny - 2, 4);
+  dim3 grid(nsk_cdiv(nx - 2, 64), gy < 64 ? gy : 64);
   k_residual_max<<<grid, 256, 0, ctx->stream>>>(Rp, Pr, divV, ld_pr_of(p), p->rho / p->dt, p->dx,
                                                p->dy, nx, ny, own_lo, own_hi, ctx->red_dev);
   NSK_LAUNCH_CHECK();
