@@ -72,8 +72,36 @@ function maxabs(c, A)                                 # maximum(abs.(A))
     check(ccall((:nsk_maxabs, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Csize_t, Ptr{Cdouble}), c.h, A.p, A.n1 * A.n2, r))
     r[]
 end
-# ... predict_V!, set_sphere!, update_∇V!, compute_res!, correct_V!, set_bc_Vel!, advect! follow
-# the same pattern with the signatures of include/nsk.h.
+const PD = Ptr{Cdouble}
+predict_V!(c, Vx, Vy, τxx, τyy, τxy, ρ, g, dt, dx, dy) =
+    check(ccall((:nsk_predict_V, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint),
+        c.h, Vx.p, Vy.p, τxx.p, τyy.p, τxy.p, ρ, g, dt, dx, dy, τxx.n1, τxx.n2))
+set_sphere!(c, C, Vx, Vy, a2, b2, ox, oy, sinβ, cosβ, lx, ly, dx, dy) =
+    check(ccall((:nsk_set_sphere, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble,
+         Cint, Cint, Cint),
+        c.h, C.p, Vx.p, Vy.p, a2, b2, ox, oy, sinβ, cosβ, lx, ly, dx, dy, C.n1, C.n2, 0))
+update_∇V!(c, ∇V, Vx, Vy, dx, dy) =
+    check(ccall((:nsk_update_divV, lib), Cint, (Ptr{Cvoid}, PD, PD, PD, Cdouble, Cdouble, Cint, Cint),
+        c.h, ∇V.p, Vx.p, Vy.p, dx, dy, ∇V.n1, ∇V.n2))
+compute_res!(c, Rp, Pr, ∇V, ρ, dt, dx, dy) =
+    check(ccall((:nsk_compute_res, lib), Cint, (Ptr{Cvoid}, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint),
+        c.h, Rp.p, Pr.p, ∇V.p, ρ, dt, dx, dy, Pr.n1, Pr.n2))
+correct_V!(c, Vx, Vy, Pr, dt, ρ, dx, dy) =
+    check(ccall((:nsk_correct_V, lib), Cint, (Ptr{Cvoid}, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint),
+        c.h, Vx.p, Vy.p, Pr.p, dt, ρ, dx, dy, Pr.n1, Pr.n2))
+set_bc_Vel!(c, Vx, Vy, Vprof) =                       # full_rows = 0: the reference's bc_x! row range
+    check(ccall((:nsk_set_bc_Vel, lib), Cint, (Ptr{Cvoid}, PD, PD, PD, Cint, Cint, Cint, Cint, Cint),
+        c.h, Vx.p, Vy.p, Vprof.p, Vy.n1, Vx.n2, 0, 0, Vx.n2))
+advect!(c, Vx, Vx_o, Vy, Vy_o, C, C_o, dt, dx, dy) =
+    check(ccall((:nsk_advect, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint, Cint),
+        c.h, Vx.p, Vx_o.p, Vy.p, Vy_o.p, C.p, C_o.p, dt, dx, dy, C.n1, C.n2, 0, C.n2))
+copy!(c, dst::DArray, src::DArray) =                  # A_o .= A
+    check(ccall((:nsk_copy, lib), Cint, (Ptr{Cvoid}, PD, PD, Csize_t), c.h, dst.p, src.p, src.n1 * src.n2))
+free!(c, d::DArray) = check(ccall((:nsk_free, lib), Cint, (Ptr{Cvoid}, PD), c.h, d.p))
+sync(c) = check(ccall((:nsk_sync, lib), Cint, (Ptr{Cvoid},), c.h))
 
 "Whole body of the time loop (the fused entry point); returns (iterations, [(iter, err)...])."
 function step!(c::Ctx, s::State, p::Params; cap=1024)
