@@ -19,8 +19,11 @@
  * Pinning: the reference's kernel tests give closed-form known answers for
  * temp_uvel_adv! (tests/test_temp_uvel_gpu.jl:47-65), set_density_viscosity!
  * (tests/test_set_density.jl:43-72) and set_tangential! (tests/
- * test_tangential_velocity.jl:84-87); tests/test_oracle_bubble.py checks this file
- * against them.  No stored outputs exist for anything else: PARITY UNPINNED beyond those.
+ * test_tangential_velocity.jl:84-87) and move_front! (scripts/tests/
+ * test_move_front_gpu.jl:74-127, rigid rotation), and input recipes without stored outputs
+ * for advect_front! and the pressure solvers (scripts/tests/test_advect_front_gpu.jl:80-123,
+ * test_solve_pressure_gpu.jl:142-180); tests/test_oracle_bubble.py checks this file against
+ * them.  No stored outputs exist for anything else: PARITY UNPINNED beyond those.
  *
  * Arrays are Julia/MATLAB column-major, 1-based: A[i,j] -> a[(j-1)*ld + (i-1)].
  * Julia semantics: x^2 is x*x, a/b*c is (a/b)*c, no FMA contraction
