@@ -13,4 +13,11 @@ extern "C" int NSK_CAT(nsk_debug_trace_k, NSK_K)(unsigned long long *out, int nt
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nsk_poisson::nsk_trace_buf),
                                   sizeof(unsigned long long) * 4 * (size_t)ntasks);
 }
+// counters of the FMA-division safety net: copies the four counters out and clears them
+extern "C" int NSK_CAT(nsk_debug_counters_k, NSK_K)(unsigned long long *out) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nsk_poisson::nsk_trace_cnt), sizeof(unsigned long long) * 4);
+  unsigned long long zero[4] = {0, 0, 0, 0};
+  if (!rc) rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(nsk_poisson::nsk_trace_cnt), zero, sizeof zero);
+  return rc;
+}
 #endif

@@ -14,6 +14,10 @@
 #define NSK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NSK_WAVES, NSK_WAVES)))
 
 namespace nsk_poisson {
+#ifdef NSK_POISSON_TRACE
+// Debug build only: [0] tasks run, [1] of them run again with IEEE division.
+static __device__ unsigned long long nsk_trace_cnt[4];
+#endif
 
 struct PoissonArgs {
   const double *pr_src;   // (ld x ny)
@@ -42,9 +46,9 @@ struct PoissonArgs {
 //             x when |1 - d*rh| <= 2^-54, which the host checks for the two divisors.
 //   DIV_FMA4  as FMA3 with q0 = RN(x*rh + RN(x*rl)), rl = RN(1/d - rh): q0 is within
 //             (1/2 + 2^-50) ulp of x/d for every divisor, hence faithful.
-// The FMA forms assume no intermediate under/overflow: they are used only while
-// 2^-900 <= |x| <= 2^900 (checked per wavefront, see SAFE_LO/SAFE_HI); otherwise
-// the wavefront falls back to DIV_IEEE for that row.
+// The FMA forms assume no intermediate under/overflow, i.e. 2^-900 <= |x| <= 2^900 for every
+// dividend (see SAFE_LO/SAFE_SPAN).  A task keeps the largest key of all its dividends and, when
+// one has left the window, is run again from its inputs with DIV_IEEE (Task::run_task).
 enum { DIV_IEEE = 0, DIV_FMA3 = 3, DIV_FMA4 = 4 };
 
 template <int DIV>
@@ -183,6 +187,7 @@ struct Task {
   unsigned lds_lane;  // DMA path: LDS byte address of this lane's 16 bytes in slot 0
 
   double P[K + 1][2][2], E[K + 1][2], D[K + 1][2][2];
+  unsigned key_acc;  // largest unsafe_key of the operands the FMA division has seen in this task
   double LP[NSLOT][2], LD[NSLOT][2], LG[NSLOT][2];  // register path: rows in flight
 
   __device__ __forceinline__ Task(const PoissonArgs &a, double2 *shared, int sx, int row0, int row1)
@@ -214,6 +219,12 @@ struct Task {
     // (such cells are carried through and not stored), the clamp only keeps the access legal.
     cc = (size_t)min(max(c0, 0), A.ld - 2);
     lds_lane = (unsigned)(uintptr_t)(lds_void_t *)shared + 16u * (unsigned)lane;
+    reset();
+  }
+
+  // Pipeline state of a task that has not started.
+  __device__ __forceinline__ void reset() {
+    key_acc = 0;
 #pragma unroll
     for (int s = 0; s <= K; s++)
 #pragma unroll
@@ -322,7 +333,7 @@ struct Task {
 
   // General step: row j (inP, inD; ignored when j > jend) arrives, pass s advances to row j-s
   // if that row is inside the task's range; every row test is evaluated.
-  template <int PH>
+  template <int PH, int QD>
   __device__ __forceinline__ void general_step(int j, const double inP[2], const double inD[2],
                                                const double2 g[K + 1]) {
     if (j <= jend) {
@@ -368,20 +379,8 @@ struct Task {
             }
           }
           const double d2y[2] = {upd[0] - low[0], upd[1] - low[1]};
-          if (DIV == DIV_IEEE) {
-            update_pair<DIV_IEEE>(d2x, d2y, dq, g[s], cen, pnew, dnew);
-          } else {
-            unsigned k0 = max(unsafe_key(d2x[0]), unsafe_key(d2y[0]));
-            unsigned k1 = max(unsafe_key(d2x[1]), unsafe_key(d2y[1]));
-            if (EDGE) {
-              k0 = inter[0] ? k0 : 0u;
-              k1 = inter[1] ? k1 : 0u;
-            }
-            if (__builtin_amdgcn_ballot_w64(max(k0, k1) >= SAFE_SPAN) == 0)
-              update_pair<DIV>(d2x, d2y, dq, g[s], cen, pnew, dnew);
-            else
-              update_pair<DIV_IEEE>(d2x, d2y, dq, g[s], cen, pnew, dnew);
-          }
+          note_operands<QD>(d2x, d2y);
+          update_pair<QD>(d2x, d2y, dq, g[s], cen, pnew, dnew);
           if (EDGE) edge_fixups(r, cen, dq, pnew, dnew);
         }
         if (s < K) {
@@ -406,46 +405,33 @@ struct Task {
     }
   }
 
-  // All K passes of one steady step with one form of division and no commit: pass s reads
-  // P[s][PH] (row r), E[s], D[s][PH] and, as the row above, pass s-1's result of this same
-  // step (pn[s-1]; the newly arrived row for s = 1).  Returns the largest unsafe_key of the
-  // operands the FMA division saw.  Nothing of the task's state is written, so the caller
-  // can evaluate the step again with IEEE division when that key is out of range.
-  template <int QD, int PH>
-  __device__ __forceinline__ unsigned steady_levels(int j, const double2 g[K + 1], double pn[K + 1][2],
-                                                    double dn[K + 1][2], double ne[K + 1][2]) const {
-    unsigned key = 0;
-#pragma unroll
-    for (int s = 1; s <= K; s++) {
-      const int r = j - s;
-      const double *cen = P[s][PH], *dq = D[s][PH];
-      const double *up = s == 1 ? P[1][PH ^ 1] : pn[s - 1];
-      const double lft = lane_prev(cen[1]), rgt = lane_next(cen[0]);
-      const double tl = cen[0] - lft, tm = cen[1] - cen[0], tr = rgt - cen[1];
-      const double d2x[2] = {tm - tl, tr - tm};
-      ne[s][0] = up[0] - cen[0];
-      ne[s][1] = up[1] - cen[1];
-      const double d2y[2] = {ne[s][0] - E[s][0], ne[s][1] - E[s][1]};
-      if (QD != DIV_IEEE) {
-        unsigned k0 = max(unsafe_key(d2x[0]), unsafe_key(d2y[0]));
-        unsigned k1 = max(unsafe_key(d2x[1]), unsafe_key(d2y[1]));
-        if (EDGE) {
-          k0 = inter[0] ? k0 : 0u;
-          k1 = inter[1] ? k1 : 0u;
-        }
-        key = max(key, max(k0, k1));
+  // The FMA forms of the division are exact only inside an exponent window (see unsafe_key).
+  // A task runs optimistically: it keeps the largest key of all operands it has divided, the
+  // driver looks at it between steps, and a task that left the window is run again from its
+  // inputs with IEEE division (the inputs are intact: a launch reads one buffer pair and writes
+  // the other).  In whole time steps from the reference's initial condition this happens in the
+  // first step only (exact zeros where the pressure has not arrived yet).
+  template <int QD>
+  __device__ __forceinline__ void note_operands(const double d2x[2], const double d2y[2]) {
+    if (QD != DIV_IEEE) {
+      unsigned k0 = max(unsafe_key(d2x[0]), unsafe_key(d2y[0]));
+      unsigned k1 = max(unsafe_key(d2x[1]), unsafe_key(d2y[1]));
+      if (EDGE) {
+        k0 = inter[0] ? k0 : 0u;
+        k1 = inter[1] ? k1 : 0u;
       }
-      update_pair<QD>(d2x, d2y, dq, g[s], cen, pn[s], dn[s]);
-      if (EDGE) edge_fixups(r, cen, dq, pn[s], dn[s]);
+      key_acc = max(key_acc, max(k0, k1));
     }
-    return key;
+  }
+  __device__ __forceinline__ bool left_safe_window() const {
+    return __builtin_amdgcn_ballot_w64(key_acc >= SAFE_SPAN) != 0;
   }
 
   // Steady step: every pass works on a row strictly inside the task's row range, away from the
-  // y boundaries, and row j-K is one of the task's output rows, so no row test is needed; one
-  // safety test covers the whole step, which keeps the K passes in one basic block so that
-  // their independent parts overlap.
-  template <int PH>
+  // y boundaries, and row j-K is one of the task's output rows, so no row test is needed and the
+  // K passes form one basic block.  Pass s reads P[s][PH] (row r), E[s], D[s][PH] and, as the
+  // row above, what pass s-1 has just written to P[s][PH^1] (the newly arrived row for s = 1).
+  template <int PH, int QD>
   __device__ __forceinline__ void steady_step(int j, const double inP[2], const double inD[2],
                                               const double2 g[K + 1]) {
 #pragma unroll
@@ -453,24 +439,31 @@ struct Task {
       P[1][PH ^ 1][v] = inP[v];
       D[1][PH ^ 1][v] = inD[v];
     }
-    double pn[K + 1][2], dn[K + 1][2], ne[K + 1][2];
-    const unsigned key = steady_levels<DIV, PH>(j, g, pn, dn, ne);
-    if (DIV != DIV_IEEE && __builtin_amdgcn_ballot_w64(key >= SAFE_SPAN) != 0)
-      steady_levels<DIV_IEEE, PH>(j, g, pn, dn, ne);
 #pragma unroll
-    for (int s = 1; s <= K; s++)
+    for (int s = 1; s <= K; s++) {
+      const int r = j - s;
+      const double *cen = P[s][PH], *up = P[s][PH ^ 1], *dq = D[s][PH];
+      const double lft = lane_prev(cen[1]), rgt = lane_next(cen[0]);
+      const double tl = cen[0] - lft, tm = cen[1] - cen[0], tr = rgt - cen[1];
+      const double d2x[2] = {tm - tl, tr - tm};
+      const double upd[2] = {up[0] - cen[0], up[1] - cen[1]};
+      const double d2y[2] = {upd[0] - E[s][0], upd[1] - E[s][1]};
+      E[s][0] = upd[0];
+      E[s][1] = upd[1];
+      note_operands<QD>(d2x, d2y);
+      double pnew[2], dnew[2];
+      update_pair<QD>(d2x, d2y, dq, g[s], cen, pnew, dnew);
+      if (EDGE) edge_fixups(r, cen, dq, pnew, dnew);
+      if (s < K) {
 #pragma unroll
-      for (int v = 0; v < 2; v++) {
-        E[s][v] = ne[s][v];
-        if (s < K) {
-          P[s + 1][PH ^ 1][v] = pn[s][v];
-          D[s + 1][PH ^ 1][v] = dn[s][v];
+        for (int v = 0; v < 2; v++) {
+          P[s + 1][PH ^ 1][v] = pnew[v];
+          D[s + 1][PH ^ 1][v] = dnew[v];
         }
+      } else if (!DMA || r >= r0) {  // (the register path enters steady steps only once r >= r0)
+        store_pair<ALIGNED>(prd, (size_t)r * ld + c0, outcol[0], outcol[1], pnew[0], pnew[1]);
+        store_dp(r, dnew);
       }
-    const int r = j - K;
-    if (!DMA || r >= r0) {  // (the register path enters steady steps only once r >= r0)
-      store_pair<ALIGNED>(prd, (size_t)r * ld + c0, outcol[0], outcol[1], pn[K][0], pn[K][1]);
-      store_dp(r, dn[K]);
     }
   }
 
@@ -481,7 +474,7 @@ struct Task {
   }
 
   // ---- register-path driver ----------------------------------------------------------------
-  template <int I, bool STEADY>
+  template <int I, bool STEADY, int QD>
   __device__ __forceinline__ void reg_steps(int j, int &ring_j, int jlast) {
     if constexpr (I < UNROLL) {
       constexpr int PH = I % 2, SL = I % NSLOT;
@@ -499,17 +492,17 @@ struct Task {
         const double inP[2] = {LP[SL][0], LP[SL][1]}, inD[2] = {LD[SL][0], LD[SL][1]};
         if (STEADY || jj + PF <= jend) load_row(jj + PF, (SL + PF) % NSLOT);
         if constexpr (STEADY)
-          steady_step<PH>(jj, inP, inD, g);
+          steady_step<PH, QD>(jj, inP, inD, g);
         else
-          general_step<PH>(jj, inP, inD, g);
+          general_step<PH, QD>(jj, inP, inD, g);
       }
       ring_j = ring_j + 1 == RING ? 0 : ring_j + 1;
-      reg_steps<I + 1, STEADY>(j, ring_j, jlast);
+      reg_steps<I + 1, STEADY, QD>(j, ring_j, jlast);
     }
   }
 
   // ---- DMA-path driver -----------------------------------------------------------------------
-  template <int PH, bool STEADY>
+  template <int PH, bool STEADY, int QD>
   __device__ __forceinline__ void dma_step(int j, int &sp, int &sg, bool &drained) {
     // Row j was requested PFD steps ago.  vmcnt counts row requests and stores together in
     // issue order; while rows are still being requested, the PFD-1 steps since have each put
@@ -533,14 +526,17 @@ struct Task {
       dma_row(j + PFD, np, ng);
     }
     if constexpr (STEADY)
-      steady_step<PH>(j, inP, inD, g);
+      steady_step<PH, QD>(j, inP, inD, g);
     else
-      general_step<PH>(j, inP, inD, g);
+      general_step<PH, QD>(j, inP, inD, g);
     sp = sp + 1 == NST ? 0 : sp + 1;
     sg = sg + 1 == NSG ? 0 : sg + 1;
   }
 
-  __device__ __forceinline__ void run() {
+  // The whole task with division form QD.  Returns false when an operand left the window in
+  // which that form is exact: the task's output is then to be produced again with IEEE division.
+  template <int QD>
+  __device__ __forceinline__ bool run() {
     const int jlast = jend + K;
     if constexpr (DMA) {
 #pragma unroll
@@ -550,11 +546,15 @@ struct Task {
       bool drained = false;
       for (int j = jstart; j <= jlast; j += 2) {
         if (steady(j) && steady(j + 1)) {
-          dma_step<0, true>(j, sp, sg, drained);
-          dma_step<1, true>(j + 1, sp, sg, drained);
+          dma_step<0, true, QD>(j, sp, sg, drained);
+          dma_step<1, true, QD>(j + 1, sp, sg, drained);
         } else {
-          dma_step<0, false>(j, sp, sg, drained);
-          if (j + 1 <= jlast) dma_step<1, false>(j + 1, sp, sg, drained);
+          dma_step<0, false, QD>(j, sp, sg, drained);
+          if (j + 1 <= jlast) dma_step<1, false, QD>(j + 1, sp, sg, drained);
+        }
+        if (QD != DIV_IEEE && left_safe_window()) {
+          vm_wait<0>();  // rows still on their way into the rings must not land in the next run
+          return false;
         }
       }
     } else {
@@ -564,10 +564,26 @@ struct Task {
       int ring_j = 0;
       for (int j = jstart; j <= jlast; j += UNROLL) {
         if (steady(j) && steady(j + UNROLL - 1))
-          reg_steps<0, true>(j, ring_j, jlast);
+          reg_steps<0, true, QD>(j, ring_j, jlast);
         else
-          reg_steps<0, false>(j, ring_j, jlast);
+          reg_steps<0, false, QD>(j, ring_j, jlast);
+        if (QD != DIV_IEEE && left_safe_window()) return false;
       }
+    }
+    return true;
+  }
+
+  __device__ __forceinline__ void run_task() {
+    const bool ok = run<DIV>();
+#ifdef NSK_POISSON_TRACE
+    if (lane == 0) {
+      atomicAdd(&nsk_trace_cnt[0], 1ull);
+      if (!ok) atomicAdd(&nsk_trace_cnt[1], 1ull);
+    }
+#endif
+    if (!ok) {
+      reset();
+      run<DIV_IEEE>();
     }
   }
 };
@@ -613,10 +629,10 @@ __global__ void __launch_bounds__(64) NSK_WAVES_ATTR k_poisson(PoissonArgs A) {
   const int cfirst = sx * WOUT - HK, clast = cfirst + 127;
   if (cfirst < 1 || clast > A.nx - 2) {
     Task<K, ALIGNED, DIV, true> t(A, shared, sx, r0, r1);
-    t.run();
+    t.run_task();
   } else {
     Task<K, ALIGNED, DIV, false> t(A, shared, sx, r0, r1);
-    t.run();
+    t.run_task();
   }
 #ifdef NSK_POISSON_TRACE
   if (threadIdx.x == 0 && blockIdx.x < NSK_POISSON_TRACE) {
@@ -677,8 +693,8 @@ inline double plan_cost(const TaskPlan &t, int nx, int ny, int num_simds) {
 // k_limit caps the automatic K (no more passes than are asked for).
 inline TaskPlan choose_plan(int nx, int ny, int num_simds, int k_forced, int k_limit, int rows_forced,
                             int edge_percent) {
-  // automatic K stops at 5: beyond that the kernel no longer fits two wavefronts per SIMD
-  int klo = 1, khi = 5;
+  // automatic K stops at 6: beyond that the kernel no longer fits two wavefronts per SIMD
+  int klo = 1, khi = 6;
   if (k_forced > 0) klo = khi = k_forced;
   if (khi > k_limit) khi = k_limit;
   if (klo > khi) klo = khi;
