@@ -15,10 +15,11 @@
 // Work decomposition: the grid is cut into column strips of 128 cells (64 lanes
 // x 2 adjacent cells) and row chunks; ONE WAVEFRONT owns one (strip, chunk)
 // task and streams through its rows bottom-to-top.  For every pass s = 1..K the
-// wave keeps a three-row window of pass s-1 in registers, so the vertical
-// neighbours are register reads and the horizontal neighbours of a lane's cell
-// pair come from the adjacent lanes by a one-lane wavefront shift (DPP).  No
-// LDS, no barriers: waves are independent.  The outer HK = K (rounded up to
+// wave keeps two rows of pass s-1 and the running y-difference in registers, so
+// the vertical neighbours are register reads and the horizontal neighbours of a
+// lane's cell pair come from the adjacent lanes by a one-lane wavefront shift
+// (DPP).  LDS only stages the wave's own input rows; no barriers: waves are
+// independent.  The outer HK = K (rounded up to
 // even) columns on each side of a strip and K rows at each end of a chunk are
 // recomputed by the neighbouring task (halo); source and destination fields
 // are distinct buffers (ping-pong), because a neighbouring task still reads
@@ -31,10 +32,6 @@
 
 int nsk_launch_maxabs(nsk_ctx *ctx, const double *A, size_t count);
 int nsk_read_maxabs(nsk_ctx *ctx, double *out);
-
-namespace {
-
-}  // namespace
 
 #include "ns_poisson_kernel.h"
 using namespace nsk_poisson;
