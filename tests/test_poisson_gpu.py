@@ -54,6 +54,21 @@ def test_poisson_iters_whole_domain(gpu, oracle, nx, ny, pitched, monkeypatch):
             assert same_bits(gdP, dP), (count, full, np.argwhere(gdP != dP)[:5])
 
 
+@pytest.mark.parametrize("nx,ny", [(3, 3000), (3000, 3), (4, 2500), (2600, 5)])
+def test_poisson_extreme_aspect_ratios(gpu, oracle, nx, ny):
+    """One interior column / one interior row: many chunks of a single strip, many strips of a
+    single chunk."""
+    rng = np.random.default_rng(nx + ny)
+    p = ns_params("NavierStokes", nx=nx, ny=ny)
+    Pr0, dP0, dv = rng_field(rng, nx, ny), rng_field(rng, nx - 2, ny - 2), rng_field(rng, nx, ny, 10.0)
+    for full in (0, 1):
+        Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
+        oracle_iters(oracle, p, Pr, dP, dv, 13, full)
+        for pitched in (False, True):
+            gPr, gdP = run_gpu(gpu, p, Pr0, dP0, dv, 13, full, pitched)
+            assert same_bits(gPr, Pr) and same_bits(gdP, dP), (full, pitched)
+
+
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_poisson_every_pass_count(oracle, k, monkeypatch):
     """Each templated pass count per launch (library option NSK_POISSON_K) on the default grid."""
