@@ -47,7 +47,7 @@ struct PoissonArgs {
 //   DIV_FMA4  as FMA3 with q0 = RN(x*rh + RN(x*rl)), rl = RN(1/d - rh): q0 is within
 //             (1/2 + 2^-50) ulp of x/d for every divisor, hence faithful.
 // The FMA forms assume no intermediate under/overflow, i.e. 2^-900 <= |x| <= 2^900 for every
-// dividend (see SAFE_LO/SAFE_SPAN).  A task keeps the largest key of all its dividends and, when
+// dividend (see EXP_LO/EXP_HI).  A task keeps the extreme exponents of all its dividends and, when
 // one has left the window, is run again from its inputs with DIV_IEEE (Task::run_task).
 enum { DIV_IEEE = 0, DIV_FMA3 = 3, DIV_FMA4 = 4 };
 
@@ -59,12 +59,12 @@ __device__ __forceinline__ double div_const(double x, double d, double rh, doubl
   return __builtin_fma(r, rh, q0);
 }
 
-// Exponent window in which the FMA forms are exact: the biased exponent field of x must lie
-// in [1023-900, 1023+900).  unsafe_key() maps a double to an unsigned that is < SAFE_SPAN
-// exactly when it does (zero, subnormal, huge, Inf and NaN all map outside).
-constexpr unsigned SAFE_LO = (1023u - 900u) << 20, SAFE_SPAN = 1800u << 20;
-__device__ __forceinline__ unsigned unsafe_key(double x) {
-  return ((unsigned)__double2hiint(x) & 0x7ff00000u) - SAFE_LO;
+// Exponent window in which the FMA forms are exact: the biased exponent field of every dividend
+// must lie in [EXP_LO, EXP_HI] = [1023-900, 1023+899].  Zero and subnormals (field 0), Inf and
+// NaN (field 2047) lie outside.  A task tracks the smallest and the largest field it has seen.
+constexpr unsigned EXP_LO = 1023u - 900u, EXP_HI = 1023u + 899u;
+__device__ __forceinline__ unsigned exponent_field(double x) {
+  return __builtin_amdgcn_ubfe((unsigned)__double2hiint(x), 20u, 11u);
 }
 
 // Value of x held by the previous / next lane of the wavefront (lane 0 resp.
@@ -187,7 +187,7 @@ struct Task {
   unsigned lds_lane;  // DMA path: LDS byte address of this lane's 16 bytes in slot 0
 
   double P[K + 1][2][2], E[K + 1][2], D[K + 1][2][2];
-  unsigned key_acc;  // largest unsafe_key of the operands the FMA division has seen in this task
+  unsigned exp_min, exp_max;  // extreme exponent fields of the dividends of the FMA division so far
   double LP[NSLOT][2], LD[NSLOT][2], LG[NSLOT][2];  // register path: rows in flight
 
   __device__ __forceinline__ Task(const PoissonArgs &a, double2 *shared, int sx, int row0, int row1)
@@ -224,7 +224,7 @@ struct Task {
 
   // Pipeline state of a task that has not started.
   __device__ __forceinline__ void reset() {
-    key_acc = 0;
+    exp_min = exp_max = 1023u;
 #pragma unroll
     for (int s = 0; s <= K; s++)
 #pragma unroll
@@ -405,8 +405,8 @@ struct Task {
     }
   }
 
-  // The FMA forms of the division are exact only inside an exponent window (see unsafe_key).
-  // A task runs optimistically: it keeps the largest key of all operands it has divided, the
+  // The FMA forms of the division are exact only inside an exponent window (see EXP_LO).
+  // A task runs optimistically: it keeps the extreme exponents of all operands it has divided, the
   // driver looks at it between steps, and a task that left the window is run again from its
   // inputs with IEEE division (the inputs are intact: a launch reads one buffer pair and writes
   // the other).  In whole time steps from the reference's initial condition this happens in the
@@ -414,17 +414,22 @@ struct Task {
   template <int QD>
   __device__ __forceinline__ void note_operands(const double d2x[2], const double d2y[2]) {
     if (QD != DIV_IEEE) {
-      unsigned k0 = max(unsafe_key(d2x[0]), unsafe_key(d2y[0]));
-      unsigned k1 = max(unsafe_key(d2x[1]), unsafe_key(d2y[1]));
-      if (EDGE) {
-        k0 = inter[0] ? k0 : 0u;
-        k1 = inter[1] ? k1 : 0u;
+      unsigned e0 = exponent_field(d2x[0]), e1 = exponent_field(d2y[0]);
+      unsigned e2 = exponent_field(d2x[1]), e3 = exponent_field(d2y[1]);
+      if (EDGE) {  // cells that are not updated hold don't-care values
+        e0 = inter[0] ? e0 : 1023u;
+        e1 = inter[0] ? e1 : 1023u;
+        e2 = inter[1] ? e2 : 1023u;
+        e3 = inter[1] ? e3 : 1023u;
       }
-      key_acc = max(key_acc, max(k0, k1));
+      exp_max = max(max(exp_max, e0), e1);
+      exp_max = max(max(exp_max, e2), e3);
+      exp_min = min(min(exp_min, e0), e1);
+      exp_min = min(min(exp_min, e2), e3);
     }
   }
   __device__ __forceinline__ bool left_safe_window() const {
-    return __builtin_amdgcn_ballot_w64(key_acc >= SAFE_SPAN) != 0;
+    return __builtin_amdgcn_ballot_w64(exp_min < EXP_LO || exp_max > EXP_HI) != 0;
   }
 
   // Steady step: every pass works on a row strictly inside the task's row range, away from the
