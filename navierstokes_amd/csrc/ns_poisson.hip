@@ -188,7 +188,7 @@ extern "C" int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, c
   // Passes per launch and task shape: forced by the options, otherwise the cheapest by the
   // planner's estimate for this grid.
   const int ep = ctx->poisson_edge_percent;
-  const TaskPlan top = choose_plan(nx, ny, ctx->num_simds, ctx->poisson_k, count < 8 ? count : 8,
+  const TaskPlan top = choose_plan(nx, ny, ctx->num_simds, aligned, ctx->poisson_k, count < 8 ? count : 8,
                                    ctx->poisson_rows, ep);
   const int kmax = top.K;
   ctx->last_plan_k = top.K;
@@ -206,7 +206,7 @@ extern "C" int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, c
     A.dp_src = src_dp;
     A.pr_dst = dst_pr;
     A.dp_dst = dst_dp;
-    const TaskPlan plan = k == top.K ? top : choose_plan(nx, ny, ctx->num_simds, k, k, ctx->poisson_rows, ep);
+    const TaskPlan plan = k == top.K ? top : choose_plan(nx, ny, ctx->num_simds, aligned, k, k, ctx->poisson_rows, ep);
     if (int rc = launch_poisson(ctx, A, aligned, div, plan)) return rc;
     left -= k;
     double *t = src_pr; src_pr = dst_pr; dst_pr = t;

@@ -696,10 +696,11 @@ inline double plan_cost(const TaskPlan &t, int nx, int ny, int num_simds) {
 
 // Passes per launch and chunk height.  k_forced / rows_forced > 0 pin the respective choice;
 // k_limit caps the automatic K (no more passes than are asked for).
-inline TaskPlan choose_plan(int nx, int ny, int num_simds, int k_forced, int k_limit, int rows_forced,
-                            int edge_percent) {
-  // automatic K stops at 6: beyond that the kernel no longer fits two wavefronts per SIMD
-  int klo = 1, khi = 6;
+inline TaskPlan choose_plan(int nx, int ny, int num_simds, bool staged, int k_forced, int k_limit,
+                            int rows_forced, int edge_percent) {
+  // automatic K stops where the kernel no longer fits two wavefronts per SIMD: 6 passes with the
+  // LDS-staged input path, 5 when the input rows travel through registers
+  int klo = 1, khi = staged ? 6 : 5;
   if (k_forced > 0) klo = khi = k_forced;
   if (khi > k_limit) khi = k_limit;
   if (klo > khi) klo = khi;
