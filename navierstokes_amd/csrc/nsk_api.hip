@@ -64,6 +64,7 @@ extern "C" int nsk_destroy(nsk_ctx *c) {
   if (c->red_host) (void)hipHostFree(c->red_host);
   if (c->pp_pr) (void)hipFree(c->pp_pr);
   if (c->pp_dp) (void)hipFree(c->pp_dp);
+  if (c->stage) (void)hipFree(c->stage);
   if (c->iter_pp) (void)hipFree(c->iter_pp);
   if (c->hist_dev) (void)hipFree(c->hist_dev);
   if (c->hist_host) (void)hipHostFree(c->hist_host);
@@ -99,6 +100,10 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
     ctx->poisson_xcd = value != 0;
     return 0;
   }
+  if (!strcmp(name, "poisson_stage")) {
+    ctx->poisson_stage = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "poisson_edge_percent")) {
     NSK_REQUIRE(value >= 0 && value <= 100, "poisson_edge_percent must be 0..100, got %d", value);
     ctx->poisson_edge_percent = value;
@@ -127,6 +132,10 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   }
   if (!strcmp(name, "poisson_rows_used")) {
     *value = ctx->last_plan_rows;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_stage")) {
+    *value = ctx->poisson_stage;
     return 0;
   }
   if (!strcmp(name, "poisson_xcd")) {

@@ -23,6 +23,11 @@ struct nsk_ctx {
   // (re)allocated on demand by the fused entry points.
   double *pp_pr = nullptr, *pp_dp = nullptr;
   size_t pp_elems = 0;
+  // Pitched staging copies of Pr, dPrdtau, divV for callers whose arrays are dense (odd leading
+  // dimension): long runs of passes are done on these and copied back.
+  double *stage = nullptr;
+  size_t stage_elems = 0;
+  int poisson_stage = 1;  // 0 = never stage (nsk_set_option "poisson_stage")
   // Per-iteration max|old-new| history of the batched iterative solvers (device + pinned host).
   unsigned long long *hist_dev = nullptr, *hist_host = nullptr;
   size_t hist_cap = 0;

@@ -243,3 +243,22 @@ def test_planner_picks_passes_per_launch_by_grid(gpu, oracle):
         assert gpu.get_option("poisson_rows_used") >= 2
     run_gpu(gpu, p, Pr0, dP0, dv, 3, 0, True)
     assert gpu.get_option("poisson_k") <= 3
+
+
+@pytest.mark.parametrize("nx,ny", [(45, 75), (130, 67), (257, 300)])
+def test_poisson_dense_arrays_staged(gpu, oracle, nx, ny):
+    """Dense arrays (the reference's own layout: odd leading dimension, dPrdτ as its own
+    (nx-2) x (ny-2) array) are iterated on pitched staging copies when the run of passes is long
+    enough; with staging switched off the register-input kernel does the same passes in place."""
+    rng = np.random.default_rng(nx * 3 + ny)
+    p = ns_params("NavierStokes", nx=nx, ny=ny)
+    Pr0, dP0, dv = rng_field(rng, nx, ny), rng_field(rng, nx - 2, ny - 2), rng_field(rng, nx, ny, 10.0)
+    Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
+    oracle_iters(oracle, p, Pr, dP, dv, 45, 0)
+    try:
+        for stage in (1, 0):
+            gpu.set_option("poisson_stage", stage)
+            gPr, gdP = run_gpu(gpu, p, Pr0, dP0, dv, 45, 0, False)
+            assert same_bits(gPr, Pr) and same_bits(gdP, dP), stage
+    finally:
+        gpu.set_option("poisson_stage", 1)
