@@ -54,7 +54,7 @@ def cpu_baseline(p, seconds_target=15.0):
         return time.perf_counter() - t0
 
     t1 = passes(2)                                   # warm-up + calibration
-    n = max(4, min(400, int(seconds_target / max(t1 / 2, 1e-4))))
+    n = max(4, min(6000, int(seconds_target / max(t1 / 2, 1e-4))))
     t = passes(n)
     t_iter = t / n
     return {"value": 40.0 * nx * ny / t_iter / 1e9, "unit": "GB/s", "cores": threads, "kind": "port",
