@@ -161,6 +161,13 @@ typedef struct nsk_ns_params {
 int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau,
                          const double *divV, const nsk_ns_params *p, int count);
 
+/* How nsk_ns_poisson_iters would cut a launch on an nx x ny window: host-only, needs no GPU (no
+ * counterpart in the reference; for tuning and tests).  num_simds = 4 x compute units;
+ * staged = 1 for pitched storage; k_forced / rows_forced = 0 leave the choice to the planner;
+ * k_limit = passes asked for.  out[6] = passes per launch, rows per task, rows per task of the
+ * two edge strips, column strips, tasks, estimated ns per pass. */
+int nsk_poisson_plan(int nx, int ny, int num_simds, int staged, int k_forced, int k_limit,
+                     int rows_forced, int edge_percent, int *out);
 /* Residual of NavierStokes.jl:89-90 on the window: writes Rp (may be NULL)
  * and returns max|Rp| over the rows this window owns (rows own_lo..own_hi,
  * 1-based window rows of Pr; pass 2 and ny-1 for a whole domain).

@@ -117,6 +117,8 @@ def load() -> C.CDLL:
     lib.nsk_create.restype = _I
     lib.nsk_destroy.argtypes = [_P]
     lib.nsk_destroy.restype = _I
+    lib.nsk_poisson_plan.argtypes = [_I] * 8 + [c_int_p]
+    lib.nsk_poisson_plan.restype = _I
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = [_P] + args
@@ -126,7 +128,17 @@ def load() -> C.CDLL:
 
 
 def exported_names() -> list[str]:
-    return ["nsk_create", "nsk_destroy", "nsk_last_error", "nsk_version"] + list(_SIGS)
+    return ["nsk_create", "nsk_destroy", "nsk_last_error", "nsk_version", "nsk_poisson_plan"] + list(_SIGS)
+
+
+def poisson_plan(nx: int, ny: int, num_simds: int = 1024, staged: bool = True, k: int = 0, k_limit: int = 8,
+                 rows: int = 0, edge_percent: int = 0) -> dict:
+    """nsk_poisson_plan: the launch geometry the fused Poisson entry points would choose (host only)."""
+    out = (C.c_int * 6)()
+    lib = load()
+    if lib.nsk_poisson_plan(nx, ny, num_simds, int(staged), k, k_limit, rows, edge_percent, out) != 0:
+        raise NskError(lib.nsk_last_error().decode())
+    return dict(zip(("k", "rows", "rows_edge", "strips", "tasks", "est_ns_per_pass"), out))
 
 
 class Context:

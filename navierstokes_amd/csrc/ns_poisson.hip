@@ -261,6 +261,22 @@ extern "C" int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, c
   return 0;
 }
 
+extern "C" int nsk_poisson_plan(int nx, int ny, int num_simds, int staged, int k_forced, int k_limit,
+                                int rows_forced, int edge_percent, int *out) {
+  NSK_REQUIRE(out != nullptr && nx >= 3 && ny >= 3 && num_simds >= 1 && k_forced >= 0 && k_forced <= 8 &&
+                  k_limit >= 1 && rows_forced >= 0,
+              "nsk_poisson_plan: bad arguments");
+  const TaskPlan t = choose_plan(nx, ny, num_simds, staged != 0, k_forced, k_limit < 8 ? k_limit : 8, rows_forced,
+                                 edge_percent);
+  out[0] = t.K;
+  out[1] = t.rows;
+  out[2] = t.rows_edge;
+  out[3] = t.nstrips;
+  out[4] = (int)t.tasks;
+  out[5] = (int)(t.est_us_per_pass * 1000.0);
+  return 0;
+}
+
 extern "C" int nsk_ns_residual(nsk_ctx *ctx, double *Rp, const double *Pr, const double *divV,
                                const nsk_ns_params *p, int own_lo, int own_hi, double *maxabs_out) {
   NSK_CTX(ctx);

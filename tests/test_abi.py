@@ -82,3 +82,30 @@ def test_header_is_plain_c(tmp_path):
     cpp = tmp_path / "h.cpp"
     cpp.write_text(f'#include "{hdr}"\nint main() {{ nsk_ns_state s{{}}; return s.Pr != nullptr; }}\n')
     subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", str(cpp)], check=True)
+
+
+def test_launch_planner_host_logic():
+    """Host side of the hot path that needs no GPU: how a launch of the multi-pass kernel is cut
+    into (strip, chunk) tasks.  All tasks of a launch are resident at once (<= 2 per SIMD); the
+    benchmark grid gets 5 or 6 passes per launch, small grids fewer passes and short tasks; forced
+    values are honoured; never more passes than asked for."""
+    from navierstokes_amd import _lib
+    big = _lib.poisson_plan(2559, 4095)
+    assert big["k"] in (5, 6) and big["tasks"] <= 2048 and big["strips"] == 23
+    assert big["rows_edge"] < big["rows"] and 2 <= big["rows"] <= 64
+    assert 15000 < big["est_ns_per_pass"] < 30000
+    small = _lib.poisson_plan(159, 255)
+    assert small["k"] <= 3 and small["rows"] <= 8 and small["strips"] == 2
+    assert _lib.poisson_plan(2559, 4095, k_limit=3)["k"] <= 3
+    assert _lib.poisson_plan(2559, 4095, staged=False)["k"] <= 5
+    forced = _lib.poisson_plan(2559, 4095, k=8, rows=200, edge_percent=50)
+    assert (forced["k"], forced["rows"], forced["rows_edge"]) == (8, 200, 100)
+    # columns 0 .. nx-2 are covered by strips of 128 - 2*halo output columns
+    for k, wout in ((1, 124), (2, 124), (3, 120), (4, 120), (5, 116), (8, 112)):
+        for nx in (3, wout + 1, wout + 2, 1000):
+            assert _lib.poisson_plan(nx, 100, k=k)["strips"] == -(-(nx - 1) // wout)
+    # slab of a taller grid on a smaller part
+    half = _lib.poisson_plan(2559, 4215, num_simds=512)
+    assert half["tasks"] <= 1024
+    with pytest.raises(_lib.NskError):
+        _lib.poisson_plan(2, 100)
