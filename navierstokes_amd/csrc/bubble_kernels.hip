@@ -208,7 +208,9 @@ __global__ void k_average(dp a, cdp b, size_t n) {
 
 // ---- single-workgroup lexicographic SOR ------------------------------------------------
 // MODE 0: pressure (code1.m:68-78 / code3_fun.jl:104-124); MODE 1: density (code3_fun.jl:224-240).
-// `a` is the unknown ((nx+2)x(ny+2), updated in place).  LDS copy of `a` when USE_LDS.
+// `a` is the unknown ((nx+2)x(ny+2), updated in place).  LDS copy of `a` when USE_LDS; the
+// coefficient arrays as well when COEF_LDS (everything fits: the reference sizes), so that a
+// diagonal costs LDS latency instead of a round trip to L2.
 struct SorArgs {
   double *a;
   const double *c1, *c2, *c3;  // pressure: tmp1, tmp2, rt;  density: fx, fy, unused
@@ -218,7 +220,7 @@ struct SorArgs {
   double *change_out;          // last max|old-new|
 };
 
-template <int MODE, bool USE_LDS>
+template <int MODE, bool USE_LDS, bool COEF_LDS>
 __global__ void __launch_bounds__(1024) k_sor(SorArgs A) {
   extern __shared__ double lds[];
   __shared__ unsigned long long red[16];
@@ -232,9 +234,19 @@ __global__ void __launch_bounds__(1024) k_sor(SorArgs A) {
     __syncthreads();
   }
   const double beta = A.beta, dx = A.dx, dy = A.dy;
-  cdp c1 = A.c1;
-  cdp c2 = A.c2;
-  cdp rt = A.c3;
+  const double *c1 = A.c1, *c2 = A.c2, *rt = A.c3;
+  if (COEF_LDS) {
+    double *l1 = lds + ncell, *l2 = lds + 2 * ncell, *l3 = lds + 3 * ncell;
+    for (size_t k = tid; k < ncell; k += nth) {
+      l1[k] = A.c1[k];
+      l2[k] = A.c2[k];
+      if (MODE == 0) l3[k] = A.c3[k];
+    }
+    __syncthreads();
+    c1 = l1;
+    c2 = l2;
+    rt = l3;
+  }
   int it = 0;
   unsigned long long last = 0;
   for (it = 1; it <= A.maxit; it++) {
@@ -447,22 +459,30 @@ int launch_sor(nsk_ctx *ctx, int mode, double *a, const double *c1, const double
   SorArgs A{a, c1, c2, c3, beta, dx, dy, maxError, nx, ny, maxit, d_sweeps, d_change};
   const size_t bytes = sizeof(double) * (size_t)(nx + 2) * (ny + 2);
   const bool use_lds = bytes <= 128 * 1024;
+  const size_t all_bytes = bytes * (mode == 0 ? 4 : 3);
+  const bool coef_lds = all_bytes <= 144 * 1024;
   int nth = nx < ny ? nx : ny;
   nth = ((nth + 63) / 64) * 64;
   if (nth > 1024) nth = 1024;
   if (nth < 64) nth = 64;
-  if (use_lds) {
-    if (mode == 0) {
-      NSK_HIP(hipFuncSetAttribute((const void *)k_sor<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-      k_sor<0, true><<<1, nth, bytes, ctx->stream>>>(A);
-    } else {
-      NSK_HIP(hipFuncSetAttribute((const void *)k_sor<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-      k_sor<1, true><<<1, nth, bytes, ctx->stream>>>(A);
-    }
+#define NSK_SOR(M, U, CL, BYTES)                                                                         \
+  do {                                                                                                   \
+    if ((BYTES) > 0)                                                                                     \
+      NSK_HIP(hipFuncSetAttribute((const void *)k_sor<M, U, CL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)(BYTES)));                                                        \
+    k_sor<M, U, CL><<<1, nth, (BYTES), ctx->stream>>>(A);                                                \
+  } while (0)
+  if (coef_lds) {
+    if (mode == 0) NSK_SOR(0, true, true, all_bytes);
+    else NSK_SOR(1, true, true, all_bytes);
+  } else if (use_lds) {
+    if (mode == 0) NSK_SOR(0, true, false, bytes);
+    else NSK_SOR(1, true, false, bytes);
   } else {
-    if (mode == 0) k_sor<0, false><<<1, nth, 0, ctx->stream>>>(A);
-    else k_sor<1, false><<<1, nth, 0, ctx->stream>>>(A);
+    if (mode == 0) NSK_SOR(0, false, false, 0);
+    else NSK_SOR(1, false, false, 0);
   }
+#undef NSK_SOR
   NSK_LAUNCH_CHECK();
   if (sweeps || change) {
     NSK_HIP(hipMemcpyAsync(ctx->red_host + 2, ctx->red_dev + 2, 16, hipMemcpyDeviceToHost, ctx->stream));
