@@ -542,7 +542,9 @@ struct Task {
   // which that form is exact: the task's output is then to be produced again with IEEE division.
   template <int QD>
   __device__ __forceinline__ bool run() {
-    const int jlast = jend + K;
+    // the last output row r1-1 leaves pass K at step r1-1+K; later steps would only advance halo
+    // rows that nobody stores
+    const int jlast = min(jend + K, r1 - 1 + K);
     if constexpr (DMA) {
 #pragma unroll
       for (int i = 0; i < PFD; i++)
@@ -680,7 +682,7 @@ inline TaskPlan plan_tasks(int K, int nx, int ny, int rows, int edge_percent) {
 }
 
 // Estimated time of a launch with this plan, per pass.  One wavefront per task, at most
-// NSK_WAVES resident per SIMD; a task streams rows + 3K - 1 row steps of K passes each.  Measured
+// NSK_WAVES resident per SIMD; a task streams rows + 2K row steps of K passes each.  Measured
 // on MI355X: 0.22 us per row and pass with one wavefront on a SIMD, 0.31 us with two; the memory
 // side moves the three inputs (with their halo re-reads) and the two outputs at about 4.8 TB/s;
 // about 3 us per launch on top.
@@ -689,7 +691,7 @@ inline double plan_cost(const TaskPlan &t, int nx, int ny, int num_simds) {
   const long slots = (long)num_simds * NSK_WAVES;
   const double rounds = (double)((t.tasks + slots - 1) / slots);
   const double per_row = t.tasks > num_simds ? 0.31 : 0.22;
-  const double alu = rounds * (t.rows + 3 * K - 1) * K * per_row;
+  const double alu = rounds * (t.rows + 2 * K) * K * per_row;
   const double mem = 8.0 * nx * ny * (3.0 * (1.0 + 2.0 * K / t.rows) * (128.0 / WOUT) + 2.0) / 4.8e6;
   return ((alu > mem ? alu : mem) + 3.0) / K;
 }
