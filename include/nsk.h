@@ -49,10 +49,16 @@ const char *nsk_version(void);
 int nsk_set_stream(nsk_ctx *ctx, void *hip_stream);
 /* Return to the stream the context created for itself. */
 int nsk_use_own_stream(nsk_ctx *ctx);
-/* Tuning knobs with no counterpart in the reference:
- *   "poisson_k"    passes of the Poisson iteration evaluated per kernel launch
- *                  (1..8, 0 = default); results are bit-identical for every value
- *   "poisson_rows" rows per wavefront task of that kernel (0 = automatic)      */
+/* Tuning and test switches with no counterpart in the reference; none of them changes a
+ * result bit.
+ *   "poisson_k"            passes of the Poisson iteration per kernel launch (1..8, 0 = chosen per
+ *                          grid); reading it back gives the value last used
+ *   "poisson_rows"         rows per wavefront task of that kernel (0 = chosen per grid)
+ *   "poisson_rows_used"    (read only) rows per task of the last launch
+ *   "poisson_edge_percent" task height of the first/last column strip in % of the others (0 = 75)
+ *   "poisson_xcd"          1 = task numbering that keeps neighbouring tasks on one XCD (default)
+ *   "poisson_stage"        1 = long runs of passes on dense arrays go through pitched copies (default)
+ *   "poisson_div"          -1 = automatic, 0 / 3 / 4 = force IEEE / 3-operation / 4-operation division */
 int nsk_set_option(nsk_ctx *ctx, const char *name, int value);
 int nsk_get_option(nsk_ctx *ctx, const char *name, int *value);
 /* Blocks until all work queued on the context's stream is done. */
@@ -139,7 +145,7 @@ int nsk_advect(nsk_ctx *ctx, double *Vx, const double *Vx_o, double *Vy,
  * Pr[ix,iy]; its rows 1, ny and columns 1, nx are unused.  The vectorised
  * kernels run when dp_embedded = 1, ld_pr is even and the three pointers are
  * 16-byte aligned; any other storage runs the same arithmetic with 8-byte
- * accesses. */
+ * accesses or, for 32 passes and more, on pitched copies kept by the context. */
 typedef struct nsk_ns_params {
   int nx, ny;        /* window extents (ny = rows held by this process) */
   int iy0, nyg;      /* global row offset and global row count          */
