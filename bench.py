@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--one-gpu", action="store_true",
                     help="rehearsal: all ranks share cuda:0 (needs --backend gloo; not a measurement)")
-    ap.add_argument("--time-steps", type=int, default=3,
+    ap.add_argument("--time-steps", type=int, default=5,
                     help="additionally run this many whole reference time steps from the IC (N=1)")
     a = ap.parse_args()
 
