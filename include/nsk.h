@@ -167,6 +167,18 @@ typedef struct nsk_ns_params {
 int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau,
                          const double *divV, const nsk_ns_params *p, int count);
 
+/* nsk_ns_poisson_iters for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same arguments, same results bit for bit; the ping-pong partners of Pr and dPrdtau
+ * live in a static device array of 2 x 4 Mi doubles (64 MiB per GPU, held until the process
+ * ends), so the call never calls hipMalloc / hipFree.  A window whose leading dimension x rows
+ * exceeds 4 Mi (4 194 304) values is rejected with an error.  Storage the vectorised kernels
+ * cannot take is iterated in place by the 8-byte kernels, never on staging copies.  All calls on
+ * one GPU share the array: calls that overlap in time on one GPU (two streams, two contexts, two
+ * threads) race.  Asynchronous. */
+int nsk_ns_poisson_iters_static(nsk_ctx *ctx, double *Pr, double *dPrdtau,
+                                const double *divV, const nsk_ns_params *p, int count);
+
 /* How nsk_ns_poisson_iters would cut a launch on an nx x ny window: host-only, needs no GPU (no
  * counterpart in the reference; for tuning and tests).  num_simds = 4 x compute units;
  * staged = 1 for pitched storage; k_forced / rows_forced = 0 leave the choice to the planner;

@@ -90,6 +90,7 @@ _SIGS = {
     "nsk_bub_average": [_P, _P, _S],
     "nsk_bub_regrid_front": [_P, _P, _P, _P, _D, _D, _I, _I, c_int_p],
     "nsk_ns_poisson_iters": [_P, _P, _P, C.POINTER(CNSParams), _I],
+    "nsk_ns_poisson_iters_static": [_P, _P, _P, C.POINTER(CNSParams), _I],
     "nsk_ns_residual": [_P, _P, _P, C.POINTER(CNSParams), _I, _I, c_double_p],
     "nsk_ns_poisson": [_P, _P, _P, _P, C.POINTER(CNSParams), c_int_p, c_double_p, c_int_p, _I, c_int_p],
     "nsk_ns_step": [C.POINTER(CNSState), C.POINTER(CNSParams), c_int_p, c_double_p, c_int_p, _I, c_int_p],

@@ -27,6 +27,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "nsk_internal.h"
 
@@ -41,6 +42,38 @@ namespace nsk_poisson {
 NSK_DECL(1) NSK_DECL(2) NSK_DECL(3) NSK_DECL(4) NSK_DECL(5) NSK_DECL(6) NSK_DECL(7) NSK_DECL(8)
 #undef NSK_DECL
 }  // namespace nsk_poisson
+
+// Ping-pong partners of Pr and dPrdτ for callers that cannot allocate (nsk_ns_poisson_iters_static):
+// two partners of NSK_STATIC_ELEMS doubles each, 64 MiB per GPU, held until the process ends.
+// In host code the array's name is only a handle for hipGetSymbolAddress; kernels and memsets use
+// the per-device address looked up once by nsk_i_static_scratch_init.
+constexpr size_t NSK_STATIC_ELEMS = (size_t)4 << 20;
+static __device__ __align__(256) double scratch[2 * NSK_STATIC_ELEMS];
+
+namespace {
+constexpr int NSK_MAX_DEVICES = 64;
+double *g_static_ptr[NSK_MAX_DEVICES];  // address of `scratch` on each device, null = not looked up
+struct StaticLayout {                   // what the last call on a device left in the partners
+  int ld, ldd, ny, embedded;
+} g_static_layout[NSK_MAX_DEVICES];
+}  // namespace
+
+// Called by nsk_create with `device` current: the address of this device's copy of `scratch`.
+int nsk_i_static_scratch_init(int device, double **out) {
+  NSK_REQUIRE(device >= 0 && device < NSK_MAX_DEVICES, "device %d beyond the %d the static scratch table holds", device,
+              NSK_MAX_DEVICES);
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!g_static_ptr[device]) {
+    double *ptr = nullptr;
+    NSK_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+    NSK_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned a null address for the static scratch");
+    g_static_ptr[device] = ptr;
+    g_static_layout[device] = StaticLayout{0, 0, 0, 0};
+  }
+  *out = g_static_ptr[device];
+  return 0;
+}
 
 namespace {
 
@@ -180,23 +213,22 @@ int staged_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double *divV, 
 
 }  // namespace
 
-extern "C" int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double *divV,
-                                    const nsk_ns_params *p, int count) {
-  NSK_CTX(ctx);
-  NSK_NONNULL(Pr, dPrdtau, divV);
-  if (int rc = check_params(p)) return rc;
-  NSK_REQUIRE(count >= 0, "negative pass count %d", count);
-  if (count == 0) return 0;
+namespace {
+
+bool vector_storage(const double *Pr, const double *dPrdtau, const double *divV, const nsk_ns_params *p) {
+  const int nx = p->nx, ld = ld_pr_of(p);
+  return p->dp_embedded && (ld % 2 == 0) && ld >= ((nx + 1) & ~1) && ((uintptr_t)Pr % 16 == 0) &&
+         ((uintptr_t)dPrdtau % 16 == 0) && ((uintptr_t)divV % 16 == 0);
+}
+
+// `count` passes in place, with part_pr / part_dp as the ping-pong partners (same layout as the
+// caller's arrays).  Allocates nothing.
+int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double *divV, const nsk_ns_params *p,
+                        int count, double *part_pr, double *part_dp) {
   const int nx = p->nx, ny = p->ny, ld = ld_pr_of(p), ldd = ld_dp_of(p);
-  const bool aligned = p->dp_embedded && (ld % 2 == 0) && ld >= ((nx + 1) & ~1) &&
-                       ((uintptr_t)Pr % 16 == 0) &&
-                       ((uintptr_t)dPrdtau % 16 == 0) && ((uintptr_t)divV % 16 == 0);
-  if (!aligned && ctx->poisson_stage && count >= STAGE_MIN_PASSES)
-    return staged_iters(ctx, Pr, dPrdtau, divV, p, count);
-  // ping-pong partners use the layout of the caller's arrays
+  const bool aligned = vector_storage(Pr, dPrdtau, divV, p);
   const size_t pr_elems = (size_t)ld * ny;
   const size_t dp_elems = p->dp_embedded ? pr_elems : (size_t)ldd * (ny - 2);
-  if (int rc = ensure_pingpong(ctx, pr_elems > dp_elems ? pr_elems : dp_elems)) return rc;
 
   PoissonArgs A;
   memset(&A, 0, sizeof A);
@@ -240,7 +272,7 @@ extern "C" int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, c
   // launches even when possible so the result lands in the caller's arrays.
   int nl = (count + kmax - 1) / kmax;
   if ((nl & 1) && count >= nl + 1) nl++;
-  double *src_pr = Pr, *src_dp = dPrdtau, *dst_pr = ctx->pp_pr, *dst_dp = ctx->pp_dp;
+  double *src_pr = Pr, *src_dp = dPrdtau, *dst_pr = part_pr, *dst_dp = part_dp;
   int left = count;
   for (int i = 0; i < nl; i++) {
     int k = (left + (nl - i) - 1) / (nl - i);
@@ -259,6 +291,59 @@ extern "C" int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, c
     NSK_HIP(hipMemcpyAsync(dPrdtau, src_dp, dp_elems * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   }
   return 0;
+}
+
+}  // namespace
+
+extern "C" int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double *divV,
+                                    const nsk_ns_params *p, int count) {
+  NSK_CTX(ctx);
+  NSK_NONNULL(Pr, dPrdtau, divV);
+  if (int rc = check_params(p)) return rc;
+  NSK_REQUIRE(count >= 0, "negative pass count %d", count);
+  if (count == 0) return 0;
+  if (!vector_storage(Pr, dPrdtau, divV, p) && ctx->poisson_stage && count >= STAGE_MIN_PASSES)
+    return staged_iters(ctx, Pr, dPrdtau, divV, p, count);
+  // ping-pong partners use the layout of the caller's arrays
+  const size_t pr_elems = (size_t)ld_pr_of(p) * p->ny;
+  const size_t dp_elems = p->dp_embedded ? pr_elems : (size_t)ld_dp_of(p) * (p->ny - 2);
+  if (int rc = ensure_pingpong(ctx, pr_elems > dp_elems ? pr_elems : dp_elems)) return rc;
+  return iters_with_partners(ctx, Pr, dPrdtau, divV, p, count, ctx->pp_pr, ctx->pp_dp);
+}
+
+// nsk_ns_poisson_iters for callers that cannot allocate: the ping-pong partners live in the
+// static device array `scratch`, so the call performs no hipMalloc / hipFree whatever the
+// arguments.  Arrays that the vectorised kernel cannot take run the register-input kernel in
+// place (the staging copies of nsk_ns_poisson_iters would have to be allocated).
+extern "C" int nsk_ns_poisson_iters_static(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double *divV,
+                                           const nsk_ns_params *p, int count) {
+  NSK_CTX(ctx);
+  NSK_NONNULL(Pr, dPrdtau, divV);
+  if (int rc = check_params(p)) return rc;
+  NSK_REQUIRE(count >= 0, "negative pass count %d", count);
+  NSK_REQUIRE(ctx->static_scratch != nullptr, "nsk_ns_poisson_iters_static: the static scratch of device %d is unavailable (%s)",
+              ctx->device, "hipGetSymbolAddress failed in nsk_create");
+  const int ld = ld_pr_of(p), ldd = ld_dp_of(p);
+  const size_t pr_elems = (size_t)ld * p->ny;
+  const size_t dp_elems = p->dp_embedded ? pr_elems : (size_t)ldd * (p->ny - 2);
+  const size_t elems = pr_elems > dp_elems ? pr_elems : dp_elems;
+  NSK_REQUIRE(elems <= NSK_STATIC_ELEMS,
+              "nsk_ns_poisson_iters_static: a window of %d x %d values (leading dimension x rows = %zu) exceeds the "
+              "static scratch of %zu values per field; use nsk_ns_poisson_iters",
+              ld, p->ny, elems, NSK_STATIC_ELEMS);
+  if (count == 0) return 0;
+  double *part_pr = ctx->static_scratch, *part_dp = ctx->static_scratch + NSK_STATIC_ELEMS;
+  // Every call on this GPU shares the partners and they keep the last call's contents.  A launch
+  // writes every value the next launch uses, but pad columns and unused rim cells are read as
+  // don't-care lanes: with a new layout they would hold whatever the last layout left there, so
+  // the part in use is cleared when the layout changes.
+  StaticLayout &last = g_static_layout[ctx->device];
+  if (last.ld != ld || last.ldd != ldd || last.ny != p->ny || last.embedded != p->dp_embedded) {
+    NSK_HIP(hipMemsetAsync(part_pr, 0, elems * sizeof(double), ctx->stream));
+    NSK_HIP(hipMemsetAsync(part_dp, 0, elems * sizeof(double), ctx->stream));
+    last = StaticLayout{ld, ldd, p->ny, p->dp_embedded};
+  }
+  return iters_with_partners(ctx, Pr, dPrdtau, divV, p, count, part_pr, part_dp);
 }
 
 extern "C" int nsk_poisson_plan(int nx, int ny, int num_simds, int staged, int k_forced, int k_limit,

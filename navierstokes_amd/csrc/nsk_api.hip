@@ -6,6 +6,8 @@
 
 static thread_local char g_err[512] = "";
 
+int nsk_i_static_scratch_init(int device, double **out);
+
 void nsk_set_error(const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -41,6 +43,8 @@ extern "C" int nsk_create(int device, nsk_ctx **out) {
     nsk_destroy(c);
     return 1;
   }
+  // (a failure here only disables nsk_ns_poisson_iters_static, which then reports it)
+  if (nsk_i_static_scratch_init(device, &c->static_scratch) != 0) c->static_scratch = nullptr;
   if (const char *k = getenv("NSK_POISSON_K")) {
     const int v = atoi(k);
     if (v >= 0 && v <= 8) c->poisson_k = v;

@@ -23,6 +23,9 @@ struct nsk_ctx {
   // (re)allocated on demand by the fused entry points.
   double *pp_pr = nullptr, *pp_dp = nullptr;
   size_t pp_elems = 0;
+  // This device's copy of the static ping-pong partners (nsk_ns_poisson_iters_static); null if
+  // its address could not be obtained.
+  double *static_scratch = nullptr;
   // Pitched staging copies of Pr, dPrdtau, divV for callers whose arrays are dense (odd leading
   // dimension): long runs of passes are done on these and copied back.
   double *stage = nullptr;
