@@ -58,7 +58,9 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *   "poisson_edge_percent" task height of the first/last column strip in % of the others (0 = 75)
  *   "poisson_xcd"          1 = task numbering that keeps neighbouring tasks on one XCD (default)
  *   "poisson_stage"        1 = long runs of passes on dense arrays go through pitched copies (default)
- *   "poisson_div"          -1 = automatic, 0 / 3 / 4 = force IEEE / 3-operation / 4-operation division */
+ *   "poisson_div"          -1 = automatic, 0 / 3 / 4 = ask for IEEE / 3-operation / 4-operation
+ *                          division; a form the two divisors dx, dy do not qualify for is replaced
+ *                          by the next exact one (3 -> 4 -> IEEE) */
 int nsk_set_option(nsk_ctx *ctx, const char *name, int value);
 int nsk_get_option(nsk_ctx *ctx, const char *name, int *value);
 /* Blocks until all work queued on the context's stream is done. */

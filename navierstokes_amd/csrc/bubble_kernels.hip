@@ -700,7 +700,7 @@ extern "C" int nsk_bub_regrid_front(nsk_ctx *ctx, double *xf, double *yf, double
                                     double *yscratch, double dx, double dy, int Nf, int cap,
                                     int *Nf_out) {
   NSK_CTX(ctx);
-  NSK_NONNULL(xf, yf);
+  NSK_NONNULL(xf, yf, xscratch, yscratch);
   NSK_REQUIRE(Nf_out != nullptr && Nf >= 1 && cap >= Nf + 2, "regrid_front: bad arguments (Nf=%d cap=%d)", Nf, cap);
   int *d_nf = reinterpret_cast<int *>(ctx->red_dev + 5);
   *reinterpret_cast<int *>(ctx->red_host + 5) = Nf;

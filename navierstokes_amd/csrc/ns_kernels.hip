@@ -395,6 +395,7 @@ extern "C" int nsk_compute_res(nsk_ctx *ctx, double *Rp, const double *Pr, const
 extern "C" int nsk_maxabs(nsk_ctx *ctx, const double *A, size_t count, double *out) {
   NSK_CTX(ctx);
   NSK_REQUIRE(out != nullptr, "nsk_maxabs: out is null");
+  if (count > 0) NSK_NONNULL(A);
   if (int rc = nsk_launch_maxabs(ctx, A, count)) return rc;
   return nsk_read_maxabs(ctx, out);
 }

@@ -149,6 +149,10 @@ int check_params(const nsk_ns_params *p) {
   return 0;
 }
 
+}  // namespace
+int nsk_i_check_params(const nsk_ns_params *p) { return check_params(p); }
+namespace {
+
 inline int ld_pr_of(const nsk_ns_params *p) { return p->ld_pr ? p->ld_pr : p->nx; }
 inline int ld_dp_of(const nsk_ns_params *p) {
   if (p->dp_embedded) return ld_pr_of(p);
@@ -257,7 +261,10 @@ int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double 
     if (div == DIV_IEEE || divy == DIV_IEEE) div = DIV_IEEE;
     else if (div == DIV_FMA4 || divy == DIV_FMA4) div = DIV_FMA4;
   }
-  if (ctx->poisson_div >= 0) div = ctx->poisson_div == 3 ? DIV_FMA3 : ctx->poisson_div == 4 ? DIV_FMA4 : DIV_IEEE;
+  // A forced form is honoured only as far as the check of the two divisors allows (3 falls back
+  // to 4, either to IEEE), so no setting can change a result bit.
+  if (ctx->poisson_div == 0) div = DIV_IEEE;
+  else if (ctx->poisson_div == 4 && div == DIV_FMA3) div = DIV_FMA4;
 
   // Passes per launch and task shape: forced by the options, otherwise the cheapest by the
   // planner's estimate for this grid.
@@ -395,7 +402,7 @@ extern "C" int nsk_ns_poisson(nsk_ctx *ctx, double *Pr, double *dPrdtau, double 
     if (nchk > 0 && done % nchk == 0) {
       double m = 0.0;
       if (int rc = nsk_ns_residual(ctx, Rp, Pr, divV, p, 2, p->ny - 1, &m)) return rc;
-      double err = m * p->ly * p->ly / p->psc;  // NavierStokes.jl:90
+      double err = m * (p->ly * p->ly) / p->psc;  // NavierStokes.jl:90, m*ly^2/psc: the power binds first
       if (nh < hist_cap) {
         if (err_hist) err_hist[nh] = err;
         if (iter_hist) iter_hist[nh] = done;

@@ -6,6 +6,8 @@ int nsk_i_update_divV(nsk_ctx *ctx, double *divV, int ld, const double *Vx, cons
 int nsk_i_correct_V(nsk_ctx *ctx, double *Vx, double *Vy, const double *Pr, int ld, double dt,
                     double rho, double dx, double dy, int nx, int ny);
 
+int nsk_i_check_params(const nsk_ns_params *p);
+
 #define NSK_TRY(call)            \
   do {                           \
     if (int rc_ = (call)) return rc_; \
@@ -18,6 +20,7 @@ extern "C" int nsk_ns_step(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_par
   NSK_REQUIRE(s != nullptr && p != nullptr, "nsk_ns_step: null argument");
   NSK_NONNULL(s->Pr, s->dPrdtau, s->C, s->C_o, s->txx, s->tyy, s->txy, s->Vx, s->Vy, s->Vx_o, s->Vy_o, s->divV,
               s->Rp, s->Vprof);
+  NSK_TRY(nsk_i_check_params(p));  // before anything modifies the state
   NSK_REQUIRE(p->iy0 == 0 && p->ny == p->nyg, "nsk_ns_step works on a whole domain");
   const int nx = p->nx, ny = p->ny;
   const int ld = p->ld_pr ? p->ld_pr : nx;

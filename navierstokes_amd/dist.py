@@ -66,6 +66,8 @@ class Slab:
 
 
 def make_slab(rank: int, world: int, ny_loc: int, halo: int) -> Slab:
+    if world > 1 and halo < 1:
+        raise ValueError(f"halo must be at least 1 row when the grid is cut into {world} slabs, got {halo}")
     if world > 1 and halo > ny_loc:
         raise ValueError(f"halo {halo} larger than the {ny_loc} rows a rank owns")
     return Slab(rank, world, ny_loc, halo if world > 1 else 0, ny_loc * world)
@@ -161,7 +163,7 @@ class SlabPoisson:
             self.iterate(chunk)
             done += chunk
             if p.nchk > 0 and done % p.nchk == 0:
-                err = self.residual() * p.ly ** 2 / p.psc
+                err = self.residual() * (p.ly * p.ly) / p.psc
                 hist.append((done, err))
                 if err < p.eps_it or not (err - err == 0.0):
                     break
@@ -254,6 +256,9 @@ class SlabNavierStokes:
 
     def __init__(self, p: NSParams, slab: Slab, backend, device, ld: int, vprof):
         self.p, self.slab, self.be, self.dev, self.ld = p, slab, backend, device, ld
+        if slab.world > 1 and slab.halo < 4:
+            # advect! needs reach + 1 <= halo - 1 valid rows and reach >= 2 (see step())
+            raise ValueError(f"a slab time step needs at least 4 halo rows, got {slab.halo}")
         nx, nw = p.nx, slab.ny_win
         z = lambda rows, cols: torch.zeros((rows, cols), dtype=torch.float64, device=device)
         # NavierStokes.jl:58-70 on the window (Pr, dPrdtau, divV pitched; the rest dense)

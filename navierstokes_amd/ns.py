@@ -148,7 +148,7 @@ class NavierStokes:
                 k.compute_res(f.Rp.ptr, f.Pr.ptr, f.divV.ptr, p.rho, p.dt, p.dx, p.dy, nx, ny)
                 m = C.c_double(0.0)
                 k.maxabs(f.Rp.ptr, (nx - 2) * (ny - 2), C.byref(m))
-                err = m.value * p.ly ** 2 / p.psc
+                err = m.value * (p.ly * p.ly) / p.psc
                 self.err_evo.append(err)
                 self.iter_evo.append(it)
                 if err < p.eps_it or not np.isfinite(err):

@@ -67,7 +67,7 @@ def ns_params(script: str = "NavierStokes", n: int = 1, nx: int | None = None,
     ly = 1.0
     rho = 1.0
     vin = 1.0
-    psc = rho * vin ** 2
+    psc = rho * (vin * vin)            # ρ*vin^2: Julia lowers x^2 to x*x
     # nondimensional
     Re = 1e6 if re6 else 1e4
     Fr = math.inf
@@ -82,9 +82,9 @@ def ns_params(script: str = "NavierStokes", n: int = 1, nx: int | None = None,
     ox = ox_ly * ly
     oy = oy_ly * ly
     mu = 1 / Re * rho * vin * ly
-    g = 1 / Fr ** 2 * vin ** 2 / ly
-    a2 = (a_ly * ly) ** 2
-    b2 = (b_ly * ly) ** 2
+    g = 1 / (Fr * Fr) * (vin * vin) / ly
+    a2 = (a_ly * ly) * (a_ly * ly)
+    b2 = (b_ly * ly) * (b_ly * ly)
     sinb, cosb = math.sin(beta), math.cos(beta)
     # numerics
     if re6:
@@ -106,7 +106,7 @@ def ns_params(script: str = "NavierStokes", n: int = 1, nx: int | None = None,
     CFL_visc = 1 / 4.1
     CFL_adv = 1.0
     dx, dy = lx / nx_, ly / ny_
-    dt = min(CFL_visc * dy ** 2 * rho / mu, CFL_adv * dy / vin)
+    dt = min(CFL_visc * (dy * dy) * rho / mu, CFL_adv * dy / vin)
     damp = 2 / ny_
     dtau = CFLtau * dy
     p = NSParams(nx=nx_, ny=ny_, niter=niter, nchk=nchk, nvis=nvis, nt=nt, nsave=nsave,

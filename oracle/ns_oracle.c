@@ -351,7 +351,7 @@ int ns_poisson(double *Pr, double *dPrdtau, double *Rp, const double *divV,
     ns_set_bc_Pr(Pr, 0.0, nx, ny, p->full_rows);
     if (nchk > 0 && iter % nchk == 0) {
       ns_compute_res(Rp, Pr, divV, p->rho, p->dt, p->dx, p->dy, nx, ny);
-      double err = ns_maxabs(Rp, (size_t)(nx - 2) * (size_t)(ny - 2)) * p->ly * p->ly / p->psc;
+      double err = ns_maxabs(Rp, (size_t)(nx - 2) * (size_t)(ny - 2)) * (p->ly * p->ly) / p->psc;  /* m*ly^2/psc: the power binds first */
       if (nh < nhist_cap) {
         if (err_hist) err_hist[nh] = err;
         if (iter_hist) iter_hist[nh] = iter;

@@ -215,3 +215,17 @@ def test_slab_time_steps_match_single_domain(tmp_path, world, halo):
         assert np.array_equal(got, getattr(ref, k)), k
     got = torch.cat([q["dP"] for q in parts]).numpy().T
     assert np.array_equal(got[1:-1, 1:-1], ref.dPrdtau)
+
+
+def test_slab_geometry_rejects_unusable_halos():
+    """A zero halo with more than one slab could never advance the Poisson loop, and a slab time
+    step needs halo rows for the back-trace of advect!."""
+    from navierstokes_amd.dist import SlabNavierStokes, make_slab
+    with pytest.raises(ValueError, match="at least 1 row"):
+        make_slab(0, 2, 40, 0)
+    with pytest.raises(ValueError, match="larger than"):
+        make_slab(0, 2, 40, 41)
+    assert make_slab(0, 1, 40, 0).halo == 0 and make_slab(0, 1, 40, 9).halo == 0
+    p = ns_params("NavierStokes", nx=9, ny=80)
+    with pytest.raises(ValueError, match="at least 4 halo rows"):
+        SlabNavierStokes(p, make_slab(0, 2, 40, 3), None, "cpu", 9, np.zeros(9))

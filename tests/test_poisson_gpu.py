@@ -111,6 +111,24 @@ def test_poisson_loop_with_checks(gpu, oracle):
     assert same_bits(dPr.get(), Pr) and same_bits(dDp.get(), dP) and same_bits(dRp.get(), Rp)
 
 
+def test_poisson_loop_err_scaling(gpu, oracle):
+    """err = max|Rp|*ly^2/psc with ly^2 evaluated first (NavierStokes.jl:90): ly = 3 separates the
+    association orders; the fused loop must report the oracle's (= the reference's) bits."""
+    p = ns_params("NavierStokes", nx=9, ny=15, ly=3.0, psc=7.0, niter=8, nchk=4)
+    nx, ny = p.nx, p.ny
+    for seed in range(12):
+        rng = np.random.default_rng(seed)
+        Pr0, dP0, dv = rng_field(rng, nx, ny), rng_field(rng, nx - 2, ny - 2), rng_field(rng, nx, ny)
+        Pr, dP, Rp = Pr0.copy(order="F"), dP0.copy(order="F"), np.zeros((nx - 2, ny - 2), order="F")
+        it, ih, eh = oracle.poisson(Pr, dP, Rp, dv, p)
+        dPr, dDp, dDv, dRp = Dev(Pr0), Dev(dP0), Dev(dv), Dev(Rp * 0)
+        cp = c_params(p)
+        iters, nh = C.c_int(0), C.c_int(0)
+        he, hi = (C.c_double * 16)(), (C.c_int * 16)()
+        gpu.ns_poisson(dPr.ptr, dDp.ptr, dRp.ptr, dDv.ptr, C.byref(cp), C.byref(iters), he, hi, 16, C.byref(nh))
+        assert iters.value == it and list(hi[: nh.value]) == ih and list(he[: nh.value]) == eh, seed
+
+
 @pytest.mark.parametrize("count", [1, 3, 4, 5, 12])
 def test_poisson_slab_windows(gpu, oracle, count):
     """A window of a taller global grid: its first/last rows are halo rows that must stay untouched,
