@@ -26,7 +26,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, halo, nx, ny_loc, steps, niter, nchk, out):
+def _worker(rank, world, port, halo, overlap, nx, ny_loc, steps, niter, nchk, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -39,7 +39,8 @@ def _worker(rank, world, port, halo, nx, ny_loc, steps, niter, nchk, out):
         slab = make_slab(rank, world, ny_loc, halo)
         ld = _pitch(nx)
         ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
-        sim = SlabNavierStokes(p, slab, HipBackend(ctx, p, ld), dev, ld, init_vprof(p))
+        sim = SlabNavierStokes(p, slab, HipBackend(ctx, p, ld), dev, ld, init_vprof(p), overlap=overlap)
+        assert sim.poisson.overlap == overlap
         iters = [sim.step() for _ in range(steps)]
         torch.cuda.synchronize()
         res = {k: sim.owned(k)[:, : {"Vx": nx + 1}.get(k, nx)].cpu() for k in ("Pr", "Vx", "Vy", "C", "dP")}
@@ -50,11 +51,14 @@ def _worker(rank, world, port, halo, nx, ny_loc, steps, niter, nchk, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,halo,nx,ny_loc", [(2, 8, 45, 40), (3, 12, 54, 30)])
-def test_slab_time_steps_on_gpu(tmp_path, world, halo, nx, ny_loc):
+@pytest.mark.parametrize("world,halo,overlap,nx,ny_loc", [(2, 8, False, 45, 40), (2, 8, True, 45, 40),
+                                                         (3, 12, True, 54, 30), (3, 15, True, 54, 30)])
+def test_slab_time_steps_on_gpu(tmp_path, world, halo, overlap, nx, ny_loc):
+    """overlap=True: boundary bands run ahead on a high-priority stream through a second library
+    context while the window is computed on the main stream; results must not change by a bit."""
     from oracle.ns_oracle import OracleSim
     steps, niter, nchk = 3, 400, 100
-    mp.spawn(_worker, args=(world, _free_port(), halo, nx, ny_loc, steps, niter, nchk, str(tmp_path)),
+    mp.spawn(_worker, args=(world, _free_port(), halo, overlap, nx, ny_loc, steps, niter, nchk, str(tmp_path)),
              nprocs=world, join=True)
     p = ns_params("NavierStokes", nx=nx, ny=ny_loc * world, niter=niter, nchk=nchk)
     ref = OracleSim(p)
