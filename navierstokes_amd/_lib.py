@@ -128,6 +128,18 @@ def load() -> C.CDLL:
     return lib
 
 
+def poisson_kernel_hash() -> str:
+    """Identifies the build of the multi-pass Poisson kernel (its source, the instantiation file and
+    the compiler flags): counter measurements are stored with it and ignored when it has changed."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    for name in ("ns_poisson_kernel.h", "ns_poisson_inst.hip", "Makefile"):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def exported_names() -> list[str]:
     return ["nsk_create", "nsk_destroy", "nsk_last_error", "nsk_version", "nsk_poisson_plan"] + list(_SIGS)
 

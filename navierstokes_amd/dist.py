@@ -17,7 +17,7 @@ the IEEE order and NaN stays the largest).
 Overlap: the rows a neighbour is waiting for are the `halo` owned rows next to an interior
 edge, final only after the last pass of a block of `halo` passes.  To have them early, each
 block first advances a *band* of 3*halo rows around each interior edge (a copy of those rows,
-run as a window of its own on a high-priority stream): after the block's passes its middle
+run as a window of its own on a second stream): after the block's passes its middle
 `halo` rows are exactly the rows to send.  They travel on a communication stream while the
 main stream runs the same passes on the whole window; the received rows are installed in the
 halo when both are done.  Bands cost 6*halo extra rows per block and rank; every value is still
@@ -170,9 +170,13 @@ class SlabPoisson:
         residual_max(Pr, divV, slab) -> float               -- max|Rp| over the owned rows
     on tensors shaped (ny_win, ld); `window` is a Slab or a Band (iy0, nyg, ny_win).
 
-    overlap: True / False / "auto" (overlapped when a rank owns at least 2*halo rows)."""
+    overlap: False (default) = passes, then the exchange; True = boundary bands ahead of the window
+    (needs 2*halo owned rows per rank); "auto" = overlapped when the geometry allows.  On one
+    MI355X the overlapped schedule costs more than it can hide (the window's launches fill every
+    wavefront slot of the chip, so band launches push them back; tools/overlap_overhead.py), hence
+    the default."""
 
-    def __init__(self, p: NSParams, slab: Slab, backend, Pr, dP, divV, overlap="auto"):
+    def __init__(self, p: NSParams, slab: Slab, backend, Pr, dP, divV, overlap=False):
         self.p, self.slab, self.be = p, slab, backend
         self.Pr, self.dP, self.divV = Pr, dP, divV
         fits = slab.world > 1 and slab.ny_loc >= 2 * slab.halo
@@ -183,6 +187,8 @@ class SlabPoisson:
         self.bands = []
         self.exchanges = 0
         self.timing = False          # True: keep an event pair per exchange (exposed_us())
+        self.loopback = False        # True: no peers; halo rows are refilled by device copies of the
+                                     # rank's own rows (timing of the compute side only, wrong values)
         self._marks = []
         if self.overlap:
             if slab.rank > 0:
@@ -190,8 +196,10 @@ class SlabPoisson:
             if slab.rank < slab.world - 1:
                 self.bands.append(Band(slab, False, Pr))
             if Pr.is_cuda:
-                # high priority: band launches are few and short, and everything downstream waits for them
-                self.band_stream = torch.cuda.Stream(device=Pr.device, priority=-1)
+                # Ordinary priority on purpose: with a high-priority band stream the second
+                # SlabPoisson of a process stalled for good on MI355X (ROCm 7.2) -- all three streams
+                # pending on each other's events -- while equal priorities never did.
+                self.band_stream = torch.cuda.Stream(device=Pr.device)
                 self.comm_stream = torch.cuda.Stream(device=Pr.device)
                 if hasattr(backend, "use_band_stream"):
                     backend.use_band_stream(self.band_stream)
@@ -200,7 +208,15 @@ class SlabPoisson:
     def _block_plain(self, n: int) -> None:
         self.be.poisson_iters(self.Pr, self.dP, self.divV, self.slab, n)
         mark = self._mark()
-        exchange_rows((self.Pr, self.dP), self.slab)
+        if self.loopback:
+            s, h = self.slab, self.slab.halo
+            for t in (self.Pr, self.dP):
+                if s.rank > 0:
+                    t[:h].copy_(t[s.own_lo:s.own_lo + h])
+                if s.rank < s.world - 1:
+                    t[s.own_hi:].copy_(t[s.own_hi - h:s.own_hi])
+        else:
+            exchange_rows((self.Pr, self.dP), self.slab)
         self._mark(mark)
 
     def _block_overlapped(self, n: int) -> None:
@@ -215,6 +231,16 @@ class SlabPoisson:
             self.be.poisson_iters(b.Pr, b.dP, self.divV[b.rows], b, n, lane=1)
         self.be.poisson_iters(self.Pr, self.dP, self.divV, self.slab, n)
         mark = self._mark()
+        if self.loopback:
+            if cuda:
+                self.comm_stream.wait_stream(self.band_stream)
+                with torch.cuda.stream(self.comm_stream):
+                    for b in self.bands:
+                        b.recv_Pr.copy_(b.Pr[b.send])
+                        b.recv_dP.copy_(b.dP[b.send])
+                main.wait_stream(self.comm_stream)
+            self._install(mark)
+            return
         gloo = dist.get_backend() == "gloo"
         stage = cuda and gloo
         if cuda and gloo:
@@ -241,6 +267,9 @@ class SlabPoisson:
                 r.wait()
             for dst, buf in landing:
                 dst.copy_(buf)
+        self._install(mark)
+
+    def _install(self, mark) -> None:
         for b in self.bands:
             h = b.h
             self.Pr[b.halo_at:b.halo_at + h].copy_(b.recv_Pr)
@@ -398,7 +427,7 @@ class SlabNavierStokes:
         poisson_iters, residual_max                          (see SlabPoisson)
     """
 
-    def __init__(self, p: NSParams, slab: Slab, backend, device, ld: int, vprof, overlap="auto"):
+    def __init__(self, p: NSParams, slab: Slab, backend, device, ld: int, vprof, overlap=False):
         self.p, self.slab, self.be, self.dev, self.ld = p, slab, backend, device, ld
         if slab.world > 1 and slab.halo < 4:
             # advect! needs reach + 1 <= halo - 1 valid rows and reach >= 2 (see step())

@@ -242,4 +242,6 @@ def test_slab_geometry_rejects_unusable_halos():
     z = torch.zeros((40 + 21, 9), dtype=torch.float64)
     with pytest.raises(ValueError, match="overlapped exchange needs"):
         SlabPoisson(p, make_slab(0, 2, 40, 21), None, z, z, z, overlap=True)
-    assert not SlabPoisson(p, make_slab(0, 2, 40, 21), None, z, z, z).overlap      # "auto" falls back
+    assert not SlabPoisson(p, make_slab(0, 2, 40, 21), None, z, z, z, overlap="auto").overlap     # falls back
+    assert SlabPoisson(p, make_slab(0, 2, 40, 20), None, z[:60], z[:60], z[:60], overlap="auto").overlap
+    assert not SlabPoisson(p, make_slab(0, 2, 40, 20), None, z[:60], z[:60], z[:60]).overlap    # default: plain

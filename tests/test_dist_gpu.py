@@ -54,7 +54,7 @@ def _worker(rank, world, port, halo, overlap, nx, ny_loc, steps, niter, nchk, ou
 @pytest.mark.parametrize("world,halo,overlap,nx,ny_loc", [(2, 8, False, 45, 40), (2, 8, True, 45, 40),
                                                          (3, 12, True, 54, 30), (3, 15, True, 54, 30)])
 def test_slab_time_steps_on_gpu(tmp_path, world, halo, overlap, nx, ny_loc):
-    """overlap=True: boundary bands run ahead on a high-priority stream through a second library
+    """overlap=True: boundary bands run ahead on a second stream through a second library
     context while the window is computed on the main stream; results must not change by a bit."""
     from oracle.ns_oracle import OracleSim
     steps, niter, nchk = 3, 400, 100
