@@ -58,9 +58,10 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *   "poisson_edge_percent" task height of the first/last column strip in % of the others (0 = 75)
  *   "poisson_xcd"          1 = task numbering that keeps neighbouring tasks on one XCD (default)
  *   "poisson_stage"        1 = long runs of passes on dense arrays go through pitched copies (default)
- *   "poisson_div"          -1 = automatic, 0 / 3 / 4 = ask for IEEE / 3-operation / 4-operation
+ *   "poisson_div"          -1 = automatic, 0 / 2 / 3 / 4 = ask for IEEE / 2- / 3- / 4-operation
  *                          division; a form the two divisors dx, dy do not qualify for is replaced
- *                          by the next exact one (3 -> 4 -> IEEE) */
+ *                          by the next exact one (2 -> 3 -> 4 -> IEEE)
+ *   "poisson_div_used"     (read only) the form the last fused Poisson call ran */
 int nsk_set_option(nsk_ctx *ctx, const char *name, int value);
 int nsk_get_option(nsk_ctx *ctx, const char *name, int *value);
 /* Blocks until all work queued on the context's stream is done. */
@@ -188,6 +189,12 @@ int nsk_ns_poisson_iters_static(nsk_ctx *ctx, double *Pr, double *dPrdtau,
  * two edge strips, column strips, tasks, estimated ns per pass. */
 int nsk_poisson_plan(int nx, int ny, int num_simds, int staged, int k_forced, int k_limit,
                      int rows_forced, int edge_percent, int *out);
+/* Which evaluation of x/d the Poisson kernel uses for the divisor d (host-only, needs no GPU; no
+ * counterpart in the reference, for tests): 0 = IEEE division, 2 / 3 / 4 = the 2-, 3- or
+ * 4-operation FMA form, each chosen only when it yields the correctly rounded quotient for every
+ * dividend (the 2-operation form after an exhaustive check of this divisor's near-midpoint
+ * quotients).  rh_out / rl_out (may be NULL) receive 1/d as an unevaluated sum hi + lo. */
+int nsk_division_form(double d, int *form_out, double *rh_out, double *rl_out);
 /* Residual of NavierStokes.jl:89-90 on the window: writes Rp (may be NULL)
  * and returns max|Rp| over the rows this window owns (rows own_lo..own_hi,
  * 1-based window rows of Pr; pass 2 and ny-1 for a whole domain).

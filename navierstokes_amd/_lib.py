@@ -120,6 +120,8 @@ def load() -> C.CDLL:
     lib.nsk_destroy.restype = _I
     lib.nsk_poisson_plan.argtypes = [_I] * 8 + [c_int_p]
     lib.nsk_poisson_plan.restype = _I
+    lib.nsk_division_form.argtypes = [_D, c_int_p, c_double_p, c_double_p]
+    lib.nsk_division_form.restype = _I
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = [_P] + args
@@ -141,7 +143,8 @@ def poisson_kernel_hash() -> str:
 
 
 def exported_names() -> list[str]:
-    return ["nsk_create", "nsk_destroy", "nsk_last_error", "nsk_version", "nsk_poisson_plan"] + list(_SIGS)
+    return ["nsk_create", "nsk_destroy", "nsk_last_error", "nsk_version", "nsk_poisson_plan",
+            "nsk_division_form"] + list(_SIGS)
 
 
 def poisson_plan(nx: int, ny: int, num_simds: int = 1024, staged: bool = True, k: int = 0, k_limit: int = 8,
@@ -152,6 +155,15 @@ def poisson_plan(nx: int, ny: int, num_simds: int = 1024, staged: bool = True, k
     if lib.nsk_poisson_plan(nx, ny, num_simds, int(staged), k, k_limit, rows, edge_percent, out) != 0:
         raise NskError(lib.nsk_last_error().decode())
     return dict(zip(("k", "rows", "rows_edge", "strips", "tasks", "est_ns_per_pass"), out))
+
+
+def division_form(d: float) -> tuple[int, float, float]:
+    """nsk_division_form: (form, rh, rl) for the divisor d (host only)."""
+    form, rh, rl = C.c_int(0), C.c_double(0.0), C.c_double(0.0)
+    lib = load()
+    if lib.nsk_division_form(float(d), C.byref(form), C.byref(rh), C.byref(rl)) != 0:
+        raise NskError(lib.nsk_last_error().decode())
+    return form.value, rh.value, rl.value
 
 
 class Context:

@@ -92,14 +92,74 @@ int launch_poisson(nsk_ctx *ctx, PoissonArgs &A, bool aligned, int div, const Ta
   return 2;
 }
 
-// Reciprocal of a divisor as hi + lo and the form of division it supports.
-int reciprocal_for(double d, double *rh, double *rl) {
+// Does q = RN(x*rh + RN(x*rl)) equal RN(x/d) for EVERY finite x (barring underflow)?
+// The argument of the final rounding is x/d (1 + e) with |e| < 2^-104 (rh + rl = 1/d to 2^-106,
+// RN(x*rl) adds at most 2^-106), so the form can only fail where x/d lies that close to a midpoint
+// between two adjacent doubles.  Write d = D 2^b and x = X 2^a with 2^52 <= D, X < 2^53.  For
+// X >= D the quotient X/D lies in [1,2) and the midpoints are O 2^-53 with O odd; for X < D it lies
+// in (1/2,1) and they are O 2^-54.  The distance to a midpoint is |X 2^s - O D| / (D 2^s), s = 53
+// or 54, a nonzero integer N over D 2^s; relative to X/D that is N / (X 2^s), which is below 2^-100
+// only for |N| < 128.  All (X, O) with X 2^s - O D = N are found from O = -N / D (mod 2^s): a handful
+// per N.  The form is evaluated on every such X and compared with the IEEE quotient; outside this set
+// x/d stays 16 times further from every midpoint than the form's error, so passing here is a proof
+// for this divisor.  (About one random divisor in a hundred fails.)
+bool two_op_division_is_exact(double d, double rh, double rl) {
+  int e2 = 0;
+  const double m = std::frexp(d, &e2);                  // d = m 2^e2, 0.5 <= m < 1
+  const unsigned long long D = (unsigned long long)std::ldexp(m, 53);
+  if (D < (1ull << 52) || D >= (1ull << 53)) return false;
+  const int k = __builtin_ctzll(D);                      // D = 2^k D', D' odd
+  if (k > 8) return false;                               // (many candidates: not worth it, use another form)
+  const unsigned long long Dp = D >> k;
+  unsigned long long inv = Dp;                           // inverse of D' modulo 2^64 (Newton)
+  for (int i = 0; i < 6; i++) inv *= 2 - Dp * inv;
+  const double dn = std::ldexp(m, 53);                   // the divisor scaled to an integer: same significand
+  for (int s = 53; s <= 54; s++) {
+    const int mb = s - k;                                // O is fixed modulo 2^mb
+    const unsigned long long mod_mask = (1ull << mb) - 1;
+    for (long long N = -128; N <= 128; N++) {
+      if (N == 0 || (N & ((1ll << k) - 1)) != 0) continue;   // X 2^s - O D = N needs 2^k | N
+      const unsigned long long O0 = ((unsigned long long)(-(N >> k)) * inv) & mod_mask;
+      for (unsigned long long O = O0; O < (1ull << 54); O += (1ull << mb)) {
+        if (O <= (1ull << 53) || !(O & 1)) continue;
+        const __int128 num = (__int128)O * (__int128)D + (__int128)N;
+        if (num <= 0 || (num & (((__int128)1 << s) - 1)) != 0) continue;
+        const unsigned long long X = (unsigned long long)(num >> s);
+        if (X < (1ull << 52) || X >= (1ull << 53)) continue;
+        // the form is invariant under scaling x and d by powers of two: test with integers X, D
+        const double x = (double)X;
+        const double rhs = std::ldexp(rh, e2 - 53), rls = std::ldexp(rl, e2 - 53);   // 1/dn as hi + lo
+        if (std::fma(x, rhs, x * rls) != x / dn) return false;
+      }
+    }
+  }
+  return true;
+}
+
+// Reciprocal of a divisor as hi + lo and the set of division forms that are exact for it
+// (bit f set = form f usable; IEEE division always is).
+unsigned reciprocal_for(double d, double *rh, double *rl) {
   *rh = 1.0 / d;
   *rl = 0.0;
-  if (!(d >= 0x1p-60 && d <= 0x1p60)) return DIV_IEEE;
+  unsigned ok = 1u << DIV_IEEE;
+  if (!(d >= 0x1p-30 && d <= 0x1p30)) return ok;
   const double e = std::fma(-d, *rh, 1.0);  // 1 - d*rh, exact
-  *rl = e / d;
-  return std::fabs(e) <= 0x1p-54 ? DIV_FMA3 : DIV_FMA4;
+  *rl = e / d;                              // e/d = 1/d - rh exactly, one rounding
+  ok |= 1u << DIV_FMA4;
+  if (std::fabs(e) <= 0x1p-54) ok |= 1u << DIV_FMA3;
+  if (two_op_division_is_exact(d, *rh, *rl)) ok |= 1u << DIV_FMA2;
+  return ok;
+}
+
+// The form to run: the requested one (or the cheapest, want < 0) if every divisor supports it,
+// otherwise the next one down the chain 2 -> 3 -> 4 -> IEEE.
+int pick_division_form(unsigned ok, int want) {
+  static const int chain[4] = {DIV_FMA2, DIV_FMA3, DIV_FMA4, DIV_IEEE};
+  int i = 0;
+  if (want >= 0)
+    while (i < 3 && chain[i] != want) i++;
+  while (i < 3 && !(ok & (1u << chain[i]))) i++;
+  return chain[i];
 }
 
 // Residual (NavierStokes.jl:145) with max|.| over the owned rows; pitched Pr/divV.
@@ -255,16 +315,11 @@ int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double 
   A.keep = 1.0 - p->damp;
   A.dtau = p->dtau;
   A.topval = 0.0;  // set_bc_Pr!(Pr, 0.0), NavierStokes.jl:87
-  int div = reciprocal_for(p->dx, &A.rdx_h, &A.rdx_l);
-  {
-    const int divy = reciprocal_for(p->dy, &A.rdy_h, &A.rdy_l);
-    if (div == DIV_IEEE || divy == DIV_IEEE) div = DIV_IEEE;
-    else if (div == DIV_FMA4 || divy == DIV_FMA4) div = DIV_FMA4;
-  }
-  // A forced form is honoured only as far as the check of the two divisors allows (3 falls back
-  // to 4, either to IEEE), so no setting can change a result bit.
-  if (ctx->poisson_div == 0) div = DIV_IEEE;
-  else if (ctx->poisson_div == 4 && div == DIV_FMA3) div = DIV_FMA4;
+  // one form for both divisors, exact for both; a requested form (testing) is honoured only if it
+  // is, so no setting can change a result bit
+  const unsigned forms = reciprocal_for(p->dx, &A.rdx_h, &A.rdx_l) & reciprocal_for(p->dy, &A.rdy_h, &A.rdy_l);
+  const int div = pick_division_form(forms, ctx->poisson_div);
+  ctx->last_div = div;
 
   // Passes per launch and task shape: forced by the options, otherwise the cheapest by the
   // planner's estimate for this grid.
@@ -351,6 +406,15 @@ extern "C" int nsk_ns_poisson_iters_static(nsk_ctx *ctx, double *Pr, double *dPr
     last = StaticLayout{ld, ldd, p->ny, p->dp_embedded};
   }
   return iters_with_partners(ctx, Pr, dPrdtau, divV, p, count, part_pr, part_dp);
+}
+
+extern "C" int nsk_division_form(double d, int *form_out, double *rh_out, double *rl_out) {
+  NSK_REQUIRE(form_out != nullptr, "nsk_division_form: form_out is null");
+  double rh = 0.0, rl = 0.0;
+  *form_out = pick_division_form(reciprocal_for(d, &rh, &rl), -1);
+  if (rh_out) *rh_out = rh;
+  if (rl_out) *rl_out = rl;
+  return 0;
 }
 
 extern "C" int nsk_poisson_plan(int nx, int ny, int num_simds, int staged, int k_forced, int k_limit,

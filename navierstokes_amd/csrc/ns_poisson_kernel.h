@@ -37,35 +37,50 @@ struct PoissonArgs {
   double rdx_h, rdx_l, rdy_h, rdy_l;  // 1/dx, 1/dy as unevaluated sums hi + lo
 };
 
-// How x/dx and x/dy are evaluated.  All three give the correctly rounded IEEE
+// How x/dx and x/dy are evaluated.  All forms give the correctly rounded IEEE
 // quotient, i.e. the same bits as the reference's `/`.
 //   DIV_IEEE  the compiler's division expansion (v_div_scale / v_rcp / Newton / v_div_fixup)
+//   DIV_FMA2  q = RN(x*rh + RN(x*rl)) with rh + rl = 1/d to 106 bits.  The argument of the final
+//             rounding is x/d (1 + e), |e| < 2^-104, so q = RN(x/d) unless x/d lies within 2^-104
+//             (relative) of a midpoint between two doubles.  For a given divisor only a handful of
+//             significands x come that close (solutions of X 2^s - O D = N for small N); the host
+//             enumerates them for a 16 times wider window and evaluates the form on each
+//             (reciprocal_for in ns_poisson.hip).  Used only for divisors that pass.
 //   DIV_FMA3  q0 = RN(x*rh); r = x - q0*d (exact, FMA); q = RN(q0 + r*rh), rh = RN(1/d).
 //             Markstein's theorem: q = RN(x/d) when rh is the correctly rounded
 //             reciprocal and q0 is a faithful rounding of x/d; q0 is faithful for every
 //             x when |1 - d*rh| <= 2^-54, which the host checks for the two divisors.
 //   DIV_FMA4  as FMA3 with q0 = RN(x*rh + RN(x*rl)), rl = RN(1/d - rh): q0 is within
 //             (1/2 + 2^-50) ulp of x/d for every divisor, hence faithful.
-// The FMA forms assume no intermediate under/overflow, i.e. 2^-900 <= |x| <= 2^900 for every
-// dividend (see EXP_LO/EXP_HI).  A task keeps the extreme exponents of all its dividends and, when
-// one has left the window, is run again from its inputs with DIV_IEEE (Task::run_task).
-enum { DIV_IEEE = 0, DIV_FMA3 = 3, DIV_FMA4 = 4 };
+// The FMA forms assume no intermediate underflow, i.e. every dividend is 0 or at least 2^-900 in
+// magnitude, and finite operands (see note_values / E_MIN_OK).  A task that cannot guarantee this
+// is run again from its inputs with DIV_IEEE (Task::run_task).
+enum { DIV_IEEE = 0, DIV_FMA2 = 2, DIV_FMA3 = 3, DIV_FMA4 = 4 };
 
 template <int DIV>
 __device__ __forceinline__ double div_const(double x, double d, double rh, double rl) {
   if (DIV == DIV_IEEE) return x / d;
+  if (DIV == DIV_FMA2) return __builtin_fma(x, rh, x * rl);
   const double q0 = DIV == DIV_FMA4 ? __builtin_fma(x, rh, x * rl) : x * rh;
   const double r = __builtin_fma(-q0, d, x);
   return __builtin_fma(r, rh, q0);
 }
 
-// Exponent window in which the FMA forms are exact: the biased exponent field of every dividend
-// must lie in [EXP_LO, EXP_HI] = [1023-900, 1023+899].  Zero and subnormals (field 0), Inf and
-// NaN (field 2047) lie outside.  A task tracks the smallest and the largest field it has seen.
-constexpr unsigned EXP_LO = 1023u - 900u, EXP_HI = 1023u + 899u;
-__device__ __forceinline__ unsigned exponent_field(double x) {
-  return __builtin_amdgcn_ubfe((unsigned)__double2hiint(x), 20u, 11u);
-}
+// When are the FMA forms safe?  Every dividend is a second difference (c-b)-(b-a) of pressure
+// values.  If every NONZERO pressure value that enters a stencil has magnitude >= 2^m, all three
+// are multiples of 2^(m-52), and so are the rounded differences: a dividend is then exactly 0
+// (harmless: every form returns 0) or at least 2^(m-52).  With m = -848 the dividends of the first
+// division are 0 or >= 2^-900 and, for divisors up to 2^30, those of the second >= 2^-930, where
+// all remainders and correction terms are still normal numbers.  So a task only tracks the smallest
+// frexp exponent of the pressure values it consumes (inputs and the intermediate passes), with 0
+// neutral: v_frexp_exp_i32_f64 returns 0 for zero, Inf and NaN and the true exponent for
+// subnormals.  |x| >= 2^-848  <=>  frexp exponent >= -847.
+// The upper side needs no tracking: huge finite operands are handled exactly (nothing overflows
+// before the quotient itself does, and then the quotient is the same infinity), and an Inf or NaN
+// operand makes every value that depends on it Inf or NaN -- in either form of division -- so a
+// task whose stored output contains a non-finite value is run again with IEEE division.
+constexpr int E_MIN_OK = -847;
+__device__ __forceinline__ bool non_finite(double x) { return __builtin_amdgcn_class(x, 0x207); }
 
 // Value of x held by the previous / next lane of the wavefront (lane 0 resp.
 // lane 63 receive 0).  v_mov_b32 with the DPP controls wave_shr:1 / wave_shl:1.
@@ -187,7 +202,8 @@ struct Task {
   unsigned lds_lane;  // DMA path: LDS byte address of this lane's 16 bytes in slot 0
 
   double P[K + 1][2][2], E[K + 1][2], D[K + 1][2][2];
-  unsigned exp_min, exp_max;  // extreme exponent fields of the dividends of the FMA division so far
+  int emin;       // smallest frexp exponent of the nonzero pressure values consumed so far
+  bool bad_out;   // a stored output was Inf or NaN
   double LP[NSLOT][2], LD[NSLOT][2], LG[NSLOT][2];  // register path: rows in flight
 
   __device__ __forceinline__ Task(const PoissonArgs &a, double2 *shared, int sx, int row0, int row1)
@@ -224,7 +240,8 @@ struct Task {
 
   // Pipeline state of a task that has not started.
   __device__ __forceinline__ void reset() {
-    exp_min = exp_max = 1023u;
+    emin = 0;
+    bad_out = false;
 #pragma unroll
     for (int s = 0; s <= K; s++)
 #pragma unroll
@@ -342,6 +359,7 @@ struct Task {
         P[1][PH ^ 1][v] = inP[v];
         D[1][PH ^ 1][v] = inD[v];
       }
+      note_values<QD>(inP);
     }
 #pragma unroll
     for (int s = 1; s <= K; s++) {
@@ -379,9 +397,9 @@ struct Task {
             }
           }
           const double d2y[2] = {upd[0] - low[0], upd[1] - low[1]};
-          note_operands<QD>(d2x, d2y);
           update_pair<QD>(d2x, d2y, dq, g[s], cen, pnew, dnew);
           if (EDGE) edge_fixups(r, cen, dq, pnew, dnew);
+          if (s < K) note_values<QD>(pnew);
         }
         if (s < K) {
 #pragma unroll
@@ -390,6 +408,7 @@ struct Task {
             D[s + 1][PH ^ 1][v] = dnew[v];
           }
         } else if (r >= r0 && r < r1) {
+          note_stored<QD>(pnew);
           const bool rowint = r >= 1 && r <= A.ny - 2;
           const bool first = r == 0, last = r == A.ny - 1;
           if (!(first && A.phys_bottom)) {
@@ -405,31 +424,30 @@ struct Task {
     }
   }
 
-  // The FMA forms of the division are exact only inside an exponent window (see EXP_LO).
-  // A task runs optimistically: it keeps the extreme exponents of all operands it has divided, the
-  // driver looks at it between steps, and a task that left the window is run again from its
-  // inputs with IEEE division (the inputs are intact: a launch reads one buffer pair and writes
-  // the other).  In whole time steps from the reference's initial condition this happens in the
-  // first step only (exact zeros where the pressure has not arrived yet).
+  // The FMA forms of the division need pressure values that are 0 or >= 2^-848 (see E_MIN_OK).
+  // A task runs optimistically: it keeps the smallest exponent of the pressure values it has
+  // consumed and whether a stored value was non-finite, the driver looks at both between steps,
+  // and a task that cannot vouch for its quotients is run again from its inputs with IEEE
+  // division (the inputs are intact: a launch reads one buffer pair and writes the other).  In
+  // whole time steps from the reference's initial condition this happens only in the first step,
+  // along the front where the pressure arrives through subnormal values.
   template <int QD>
-  __device__ __forceinline__ void note_operands(const double d2x[2], const double d2y[2]) {
+  __device__ __forceinline__ void note_values(const double x[2]) {
     if (QD != DIV_IEEE) {
-      unsigned e0 = exponent_field(d2x[0]), e1 = exponent_field(d2y[0]);
-      unsigned e2 = exponent_field(d2x[1]), e3 = exponent_field(d2y[1]);
-      if (EDGE) {  // cells that are not updated hold don't-care values
-        e0 = inter[0] ? e0 : 1023u;
-        e1 = inter[0] ? e1 : 1023u;
-        e2 = inter[1] ? e2 : 1023u;
-        e3 = inter[1] ? e3 : 1023u;
+      int e0 = __builtin_amdgcn_frexp_exp(x[0]), e1 = __builtin_amdgcn_frexp_exp(x[1]);
+      if (EDGE) {  // cells outside the domain hold don't-care values
+        e0 = indom[0] ? e0 : 0;
+        e1 = indom[1] ? e1 : 0;
       }
-      exp_max = max(max(exp_max, e0), e1);
-      exp_max = max(max(exp_max, e2), e3);
-      exp_min = min(min(exp_min, e0), e1);
-      exp_min = min(min(exp_min, e2), e3);
+      emin = min(emin, min(e0, e1));
     }
   }
+  template <int QD>
+  __device__ __forceinline__ void note_stored(const double x[2]) {
+    if (QD != DIV_IEEE) bad_out |= (outcol[0] && non_finite(x[0])) || (outcol[1] && non_finite(x[1]));
+  }
   __device__ __forceinline__ bool left_safe_window() const {
-    return __builtin_amdgcn_ballot_w64(exp_min < EXP_LO || exp_max > EXP_HI) != 0;
+    return __builtin_amdgcn_ballot_w64(emin < E_MIN_OK || bad_out) != 0;
   }
 
   // Steady step: every pass works on a row strictly inside the task's row range, away from the
@@ -444,6 +462,7 @@ struct Task {
       P[1][PH ^ 1][v] = inP[v];
       D[1][PH ^ 1][v] = inD[v];
     }
+    note_values<QD>(inP);
 #pragma unroll
     for (int s = 1; s <= K; s++) {
       const int r = j - s;
@@ -455,17 +474,18 @@ struct Task {
       const double d2y[2] = {upd[0] - E[s][0], upd[1] - E[s][1]};
       E[s][0] = upd[0];
       E[s][1] = upd[1];
-      note_operands<QD>(d2x, d2y);
       double pnew[2], dnew[2];
       update_pair<QD>(d2x, d2y, dq, g[s], cen, pnew, dnew);
       if (EDGE) edge_fixups(r, cen, dq, pnew, dnew);
       if (s < K) {
+        note_values<QD>(pnew);
 #pragma unroll
         for (int v = 0; v < 2; v++) {
           P[s + 1][PH ^ 1][v] = pnew[v];
           D[s + 1][PH ^ 1][v] = dnew[v];
         }
       } else if (!DMA || r >= r0) {  // (the register path enters steady steps only once r >= r0)
+        note_stored<QD>(pnew);
         store_pair<ALIGNED>(prd, (size_t)r * ld + c0, outcol[0], outcol[1], pnew[0], pnew[1]);
         store_dp(r, dnew);
       }
@@ -743,11 +763,13 @@ int launch_k(nsk_ctx *ctx, PoissonArgs &A, bool aligned, int div, const TaskPlan
   const unsigned tasks = (unsigned)plan.tasks;
 #define NSK_LAUNCH(AL, DV) k_poisson<K, AL, DV><<<tasks, 64, 0, ctx->stream>>>(A)
   if (aligned) {
-    if (div == DIV_FMA3) NSK_LAUNCH(true, DIV_FMA3);
+    if (div == DIV_FMA2) NSK_LAUNCH(true, DIV_FMA2);
+    else if (div == DIV_FMA3) NSK_LAUNCH(true, DIV_FMA3);
     else if (div == DIV_FMA4) NSK_LAUNCH(true, DIV_FMA4);
     else NSK_LAUNCH(true, DIV_IEEE);
   } else {
-    if (div == DIV_FMA3) NSK_LAUNCH(false, DIV_FMA3);
+    if (div == DIV_FMA2) NSK_LAUNCH(false, DIV_FMA2);
+    else if (div == DIV_FMA3) NSK_LAUNCH(false, DIV_FMA3);
     else if (div == DIV_FMA4) NSK_LAUNCH(false, DIV_FMA4);
     else NSK_LAUNCH(false, DIV_IEEE);
   }

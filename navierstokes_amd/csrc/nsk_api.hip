@@ -114,8 +114,8 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
     return 0;
   }
   if (!strcmp(name, "poisson_div")) {
-    NSK_REQUIRE(value == -1 || value == 0 || value == 3 || value == 4,
-                "poisson_div must be -1 (automatic), 0, 3 or 4, got %d", value);
+    NSK_REQUIRE(value == -1 || value == 0 || value == 2 || value == 3 || value == 4,
+                "poisson_div must be -1 (automatic), 0, 2, 3 or 4, got %d", value);
     ctx->poisson_div = value;
     return 0;
   }
@@ -152,6 +152,10 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   }
   if (!strcmp(name, "poisson_div")) {
     *value = ctx->poisson_div;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_div_used")) {
+    *value = ctx->last_div;
     return 0;
   }
   nsk_set_error("nsk_get_option: unknown option '%s'", name);

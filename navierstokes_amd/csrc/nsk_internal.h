@@ -38,7 +38,8 @@ struct nsk_ctx {
   size_t iter_pp_elems = 0;
   int poisson_k = 0;     // passes per launch, 0 = chosen per grid (NSK_POISSON_K / nsk_set_option)
   int last_plan_k = 0, last_plan_rows = 0;  // what the last fused Poisson call used (nsk_get_option)
-  int poisson_div = -1;  // -1 = automatic; 0 / 3 / 4 force a division form (testing)
+  int poisson_div = -1;  // -1 = automatic; 0 / 2 / 3 / 4 ask for a division form (testing)
+  int last_div = -1;     // form the last fused Poisson call used (nsk_get_option "poisson_div_used")
   int poisson_edge_percent = 0;  // rows per task of the edge strips in % of poisson_rows, 0 = default
   int poisson_xcd = 1;   // XCD-aware task numbering of the Poisson kernel (0 = plain)
   int poisson_rows = 0;  // rows per task chunk, 0 = automatic (NSK_POISSON_ROWS / nsk_set_option)

@@ -84,7 +84,7 @@ def test_misuse_is_reported_not_computed(gpu):
     with pytest.raises(_lib.NskError):
         gpu.set_option("poisson_k", 9)
     with pytest.raises(_lib.NskError):
-        gpu.set_option("poisson_div", 2)
+        gpu.set_option("poisson_div", 1)
     # grids the kernels cannot take, null arrays, bad pitch
     p = ns_params("NavierStokes", nx=33, ny=41)
     buf = C.c_void_p()

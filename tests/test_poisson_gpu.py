@@ -157,11 +157,12 @@ def test_poisson_slab_windows(gpu, oracle, count):
                 assert same_bits(gPr[:, -1], wPr[:, -1])
 
 
-@pytest.mark.parametrize("div", [0, 3, 4])
+@pytest.mark.parametrize("div", [0, 2, 3, 4])
 def test_poisson_division_forms(oracle, div):
     """x/dx/dx is evaluated either by IEEE division or by an FMA sequence that yields the same
     correctly rounded quotient.  Forced forms on: ordinary data, data near the underflow range
-    (where the FMA form must hand over to IEEE division), exact zeros, and huge values."""
+    and subnormal data (where the FMA form must hand over to IEEE division), exact zeros, huge
+    values, and fields that contain Inf / NaN."""
     import torch
     from navierstokes_amd import _lib
     ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
@@ -170,10 +171,16 @@ def test_poisson_division_forms(oracle, div):
         nx, ny = 153, 255
         p = ns_params("NavierStokes")
         rng = np.random.default_rng(100 + div)
-        for scale, zero_frac in [(1.0, 0.0), (1e-290, 0.0), (1e-305, 0.3), (1e-318, 0.5), (1.0, 0.7), (1e290, 0.0)]:
+        for scale, zero_frac in [(1.0, 0.0), (1e-250, 0.0), (1e-262, 0.2), (1e-290, 0.0), (1e-305, 0.3), (1e-318, 0.5),
+                                 (1.0, 0.7), (1e290, 0.0), (1e300, 0.0), (-1.0, 0.0)]:
+            special = scale < 0
+            scale = abs(scale)
             Pr0 = rng_field(rng, nx, ny, scale)
             dP0 = rng_field(rng, nx - 2, ny - 2, scale)
             dv = rng_field(rng, nx, ny, scale)
+            if special:     # Inf and NaN somewhere in the field, a subnormal island elsewhere
+                Pr0[40, 60], Pr0[100, 200], Pr0[120, 30] = np.inf, np.nan, -np.inf
+                Pr0[60:70, 120:130] *= 1e-315
             if zero_frac:
                 Pr0[rng.random((nx, ny)) < zero_frac] = 0.0
                 Pr0[:, ny // 2:] = 0.0
@@ -184,8 +191,11 @@ def test_poisson_division_forms(oracle, div):
                 with np.errstate(all="ignore"):
                     oracle_iters(oracle, p, Pr, dP, dv, 9, 0)
                 gPr, gdP = run_gpu(ctx, p, Pr0, dP0, dv, 9, 0, pitched)
-                if scale < 1e200:
+                assert ctx.get_option("poisson_div_used") == div      # dx = dy = 1/255 qualifies for every form
+                if scale < 1e200 and not special:
                     assert np.isfinite(Pr).all()
+                # Inf and NaN must sit in the same cells (same_bits lets any NaN equal any NaN)
+                assert np.array_equal(np.isnan(gPr), np.isnan(Pr)) and np.array_equal(np.isinf(gPr), np.isinf(Pr))
                 assert same_bits(gPr, Pr), (scale, zero_frac, pitched)
                 assert same_bits(gdP, dP), (scale, zero_frac, pitched)
     finally:
