@@ -140,6 +140,9 @@ __device__ __forceinline__ v4i_t lds_read16_nowait(unsigned byte_addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr) : "memory");
   return v;
 }
+__device__ __forceinline__ void lds_write16(unsigned byte_addr, v4i_t v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(byte_addr), "v"(v) : "memory");
+}
 __device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // Re-defines x behind the wait so that no use of it can be scheduled ahead of the wait.
 __device__ __forceinline__ void pin_after_wait(v4i_t &x) { asm volatile("" : "+v"(x)); }
@@ -274,12 +277,16 @@ struct Task {
   }
 
   // Row j of Pr and dPrdτ (slot sp) and ρ/dt*∇V of rows j-1 .. j-K (slots behind sg).
+  // The ∇V row that has just arrived (row j, slot sg) is replaced in its slot by ρ/dt*∇V
+  // (NavierStokes.jl:135), so the K passes that use it read the product instead of forming it K
+  // times; LDS operations of a wave execute in order, so the reads of the following steps see it.
   __device__ __forceinline__ void dma_fetch(int sp, int sg, bool want_row, double inP[2], double inD[2],
                                             double2 g[K + 1]) {
-    v4i_t vp = {0, 0, 0, 0}, vd = {0, 0, 0, 0}, vg[K + 1];
+    v4i_t vp = {0, 0, 0, 0}, vd = {0, 0, 0, 0}, vg[K + 1], vraw = {0, 0, 0, 0};
     if (want_row) {
       vp = lds_read16_nowait(lds_lane + (unsigned)sp * 1024u);
       vd = lds_read16_nowait(lds_lane + (unsigned)(NST + sp) * 1024u);
+      vraw = lds_read16_nowait(lds_lane + (unsigned)(2 * NST + sg) * 1024u);
     }
 #pragma unroll
     for (int s = 1; s <= K; s++) {
@@ -290,19 +297,22 @@ struct Task {
     lds_wait_all();
     pin_after_wait(vp);
     pin_after_wait(vd);
+    pin_after_wait(vraw);
 #pragma unroll
     for (int s = 1; s <= K; s++) pin_after_wait(vg[s]);
+    if (want_row) {
+      const double2 r = as_double2(vraw);
+      const double g0 = A.rho_dt * r.x, g1 = A.rho_dt * r.y;
+      const v4i_t w = {__double2loint(g0), __double2hiint(g0), __double2loint(g1), __double2hiint(g1)};
+      lds_write16(lds_lane + (unsigned)(2 * NST + sg) * 1024u, w);
+    }
     const double2 p = as_double2(vp), d = as_double2(vd);
     inP[0] = p.x;
     inP[1] = p.y;
     inD[0] = d.x;
     inD[1] = d.y;
 #pragma unroll
-    for (int s = 1; s <= K; s++) {
-      // ρ/dt*∇V (NavierStokes.jl:135): the same product in every pass
-      const double2 r = as_double2(vg[s]);
-      g[s] = make_double2(A.rho_dt * r.x, A.rho_dt * r.y);
-    }
+    for (int s = 1; s <= K; s++) g[s] = as_double2(vg[s]);
   }
 
   // One pass of one row: NavierStokes.jl:135 then :140, association as written there:

@@ -12,7 +12,7 @@ from navierstokes_amd import _lib, ns_params
 from navierstokes_amd.ns import _pitch, c_params
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--k", type=int, default=4)
+ap.add_argument("--k", type=int, default=6)
 ap.add_argument("--rows", type=int, default=0)
 ap.add_argument("--xcd", type=int, default=1)
 ap.add_argument("--launches", type=int, default=20)

@@ -20,10 +20,13 @@ ap.add_argument("--launches", type=int, default=200)
 ap.add_argument("--div", type=int, default=-1)
 ap.add_argument("--edge", default="0")
 ap.add_argument("--xcd", default="1")
+ap.add_argument("--ny", type=int, default=0, help="grid rows (default: the script's 256n-1)")
 ap.add_argument("--dense", action="store_true", help="dense (unaligned) storage instead of pitched")
 a = ap.parse_args()
 
 p = ns_params("NavierStokes_Re6", n=a.n)
+if a.ny:    # another height with the scalars of the script's grid (same divisors, same division form)
+    p = p.with_(ny=a.ny)
 nx, ny = p.nx, p.ny
 ld = nx if a.dense else _pitch(nx)
 torch.cuda.set_device(0)
