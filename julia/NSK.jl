@@ -114,4 +114,158 @@ function step!(c::Ctx, s::State, p::Params; cap=1024)
     iters[], collect(zip(its[1:n], errs[1:n]))
 end
 
+# ---- fused Poisson entry points, options, streams ------------------------------------------
+"`count` passes of NavierStokes.jl:85-87 without a residual check."
+poisson_iters!(c, Pr, dPrdτ, ∇V, p::Params, count) =
+    check(ccall((:nsk_ns_poisson_iters, lib), Cint, (Ptr{Cvoid}, PD, PD, PD, Ref{Params}, Cint),
+        c.h, Pr.p, dPrdτ.p, ∇V.p, p, count))
+"The same for callers that must not allocate (windows of at most 4 Mi values per field)."
+poisson_iters_static!(c, Pr, dPrdτ, ∇V, p::Params, count) =
+    check(ccall((:nsk_ns_poisson_iters_static, lib), Cint, (Ptr{Cvoid}, PD, PD, PD, Ref{Params}, Cint),
+        c.h, Pr.p, dPrdτ.p, ∇V.p, p, count))
+function residual(c, Rp, Pr, ∇V, p::Params, own_lo, own_hi)     # compute_res! + maximum(abs.(Rp))
+    r = Ref{Cdouble}(0.0)
+    check(ccall((:nsk_ns_residual, lib), Cint, (Ptr{Cvoid}, PD, PD, PD, Ref{Params}, Cint, Cint, Ptr{Cdouble}),
+        c.h, Rp.p, Pr.p, ∇V.p, p, own_lo, own_hi, r))
+    r[]
+end
+"The Poisson loop NavierStokes.jl:84-95; returns (iterations, [(iter, err)...])."
+function poisson!(c, Pr, dPrdτ, Rp, ∇V, p::Params; cap=1024)
+    iters = Ref{Cint}(0); nh = Ref{Cint}(0)
+    errs = Vector{Cdouble}(undef, cap); its = Vector{Cint}(undef, cap)
+    check(ccall((:nsk_ns_poisson, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, PD, Ref{Params}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cint}, Cint, Ptr{Cint}),
+        c.h, Pr.p, dPrdτ.p, Rp.p, ∇V.p, p, iters, errs, its, cap, nh))
+    n = min(nh[], cap)
+    iters[], collect(zip(its[1:n], errs[1:n]))
+end
+update_∇V_ld!(c, ∇V, ld, Vx, Vy, dx, dy, nx, ny) =
+    check(ccall((:nsk_update_divV_ld, lib), Cint, (Ptr{Cvoid}, PD, Cint, PD, PD, Cdouble, Cdouble, Cint, Cint),
+        c.h, ∇V.p, ld, Vx.p, Vy.p, dx, dy, nx, ny))
+correct_V_ld!(c, Vx, Vy, Pr, ld, dt, ρ, dx, dy, nx, ny) =
+    check(ccall((:nsk_correct_V_ld, lib), Cint, (Ptr{Cvoid}, PD, PD, PD, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint),
+        c.h, Vx.p, Vy.p, Pr.p, ld, dt, ρ, dx, dy, nx, ny))
+set_option!(c, name::String, v) =
+    check(ccall((:nsk_set_option, lib), Cint, (Ptr{Cvoid}, Cstring, Cint), c.h, name, v))
+function get_option(c, name::String)
+    r = Ref{Cint}(0)
+    check(ccall((:nsk_get_option, lib), Cint, (Ptr{Cvoid}, Cstring, Ptr{Cint}), c.h, name, r))
+    r[]
+end
+set_stream!(c, hip_stream::Ptr{Cvoid}) = check(ccall((:nsk_set_stream, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), c.h, hip_stream))
+use_own_stream!(c) = check(ccall((:nsk_use_own_stream, lib), Cint, (Ptr{Cvoid},), c.h))
+version() = unsafe_string(ccall((:nsk_version, lib), Cstring, ()))
+function poisson_plan(nx, ny; num_simds=1024, staged=1, k=0, k_limit=8, rows=0, edge_percent=0)
+    out = Vector{Cint}(undef, 6)
+    check(ccall((:nsk_poisson_plan, lib), Cint, (Cint, Cint, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Cint}),
+        nx, ny, num_simds, staged, k, k_limit, rows, edge_percent, out))
+    out
+end
+function division_form(d)
+    f = Ref{Cint}(0); rh = Ref{Cdouble}(0.0); rl = Ref{Cdouble}(0.0)
+    check(ccall((:nsk_division_form, lib), Cint, (Cdouble, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cdouble}), d, f, rh, rl))
+    f[], rh[], rl[]
+end
+
+# ---- bubble / drop solvers: scripts/DNS.jl (in the form scripts/code1.m states) and ----------
+# ---- scripts/code3_fun.jl; one stub per kernel, argument order of the Julia kernels ----------
+vec(c::Ctx, n) = zeros(c, n, 1)
+"set_density! DNS.jl:128-137; with m also set_density_viscosity! code3_fun.jl:8-18 (m = nothing: density only)"
+set_density!(c, r, m, xc, yc, x, y, rad, ρ₂, m₂, nx, ny) =
+    check(ccall((:nsk_bub_set_density, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, Cdouble, Cdouble, PD, PD, Cdouble, Cdouble, Cdouble, Cint, Cint),
+        c.h, r.p, m === nothing ? Ptr{Cdouble}(C_NULL) : m.p, xc, yc, x.p, y.p, rad, ρ₂, m₂, nx, ny))
+set_tangential!(c, u, v, usouth, unorth, vwest, veast, nx, ny) =
+    check(ccall((:nsk_bub_set_tangential, lib), Cint, (Ptr{Cvoid}, PD, PD, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint),
+        c.h, u.p, v.p, usouth, unorth, vwest, veast, nx, ny))
+"temp_uvel! + temp_vvel! DNS.jl:159-179"
+temp_vel!(c, ut, vt, u, v, r, dt, dx, dy, gx, gy, m0, nx, ny) =
+    check(ccall((:nsk_bub_temp_vel, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint),
+        c.h, ut.p, vt.p, u.p, v.p, r.p, dt, dx, dy, gx, gy, m0, nx, ny))
+"temp_uvel_adv! + temp_vvel_adv! code3_fun.jl:37-62"
+temp_vel_adv!(c, ut, vt, u, v, r, dt, dx, dy, fx, fy, gx, gy, rro, nx, ny) =
+    check(ccall((:nsk_bub_temp_vel_adv, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, PD, PD, Cdouble, Cdouble, Cdouble, Cint, Cint),
+        c.h, ut.p, vt.p, u.p, v.p, r.p, dt, dx, dy, fx.p, fy.p, gx, gy, rro, nx, ny))
+"temp_uvel_diff! + temp_vvel_diff! code3_fun.jl:64-90"
+temp_vel_diff!(c, ut, vt, u, v, r, dt, dx, dy, m, nx, ny) =
+    check(ccall((:nsk_bub_temp_vel_diff, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, PD, Cint, Cint),
+        c.h, ut.p, vt.p, u.p, v.p, r.p, dt, dx, dy, m.p, nx, ny))
+set_boundary!(c, rt, r, lrg, nx, ny) =
+    check(ccall((:nsk_bub_set_boundary, lib), Cint, (Ptr{Cvoid}, PD, PD, Cdouble, Cint, Cint), c.h, rt.p, r.p, lrg, nx, ny))
+compute_sources!(c, tmp1, tmp2, rt, ut, vt, dt, dx, dy, nx, ny) =
+    check(ccall((:nsk_bub_compute_sources, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cint, Cint),
+        c.h, tmp1.p, tmp2.p, rt.p, ut.p, vt.p, dt, dx, dy, nx, ny))
+"The whole pressure loop (DNS.jl:83-93 / code3_fun.jl:104-124); returns (sweeps, last max|old-new|)."
+function solve_pressure!(c, p, tmp1, tmp2, rt, β, dx, dy, nx, ny, maxit, maxError; solver=:sor)
+    sw = Ref{Cint}(0); ch = Ref{Cdouble}(0.0)
+    if solver == :sor
+        check(ccall((:nsk_bub_solve_pressure, lib), Cint,
+            (Ptr{Cvoid}, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint, Cdouble, Ptr{Cint}, Ptr{Cdouble}),
+            c.h, p.p, tmp1.p, tmp2.p, rt.p, β, dx, dy, nx, ny, maxit, maxError, sw, ch))
+    else    # red/black order, code3_perf_gpu.jl:129-183
+        check(ccall((:nsk_bub_solve_pressure_rb, lib), Cint,
+            (Ptr{Cvoid}, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint, Cdouble, Ptr{Cint}, Ptr{Cdouble}),
+            c.h, p.p, tmp1.p, tmp2.p, rt.p, β, dx, dy, nx, ny, maxit, maxError, sw, ch))
+    end
+    sw[], ch[]
+end
+"update_dPdτ! + update_p! with their loop, code1_perf_gpu.jl:98-118,228-242"
+function pt_pressure!(c, p, dPdτ, tmp1, rt, dτ, damp, dx, dy, nx, ny, maxit, maxError)
+    it = Ref{Cint}(0); ch = Ref{Cdouble}(0.0)
+    check(ccall((:nsk_bub_pt_pressure, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint, Cdouble, Ptr{Cint}, Ptr{Cdouble}),
+        c.h, p.p, dPdτ.p, tmp1.p, rt.p, dτ, damp, dx, dy, nx, ny, maxit, maxError, it, ch))
+    it[], ch[]
+end
+"correct_uvel! + correct_vvel! DNS.jl:190-202"
+correct_vel!(c, u, v, ut, vt, p, r, dt, dx, dy, nx, ny) =
+    check(ccall((:nsk_bub_correct_vel, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cint, Cint),
+        c.h, u.p, v.p, ut.p, vt.p, p.p, r.p, dt, dx, dy, nx, ny))
+advect_density!(c, r, ro, u, v, dt, dx, dy, m0, nx, ny) =
+    check(ccall((:nsk_bub_advect_density, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint),
+        c.h, r.p, ro.p, u.p, v.p, dt, dx, dy, m0, nx, ny))
+velocity!(c, uu, vv, u, v, nx, ny) =
+    check(ccall((:nsk_bub_velocity, lib), Cint, (Ptr{Cvoid}, PD, PD, PD, PD, Cint, Cint), c.h, uu.p, vv.p, u.p, v.p, nx, ny))
+"tangents + spreading of the surface tension, code3_fun.jl:365-401"
+surface_tension!(c, fx, fy, tx, ty, xf, yf, σ, dx, dy, nx, ny, Nf) =
+    check(ccall((:nsk_bub_surface_tension, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint),
+        c.h, fx.p, fy.p, tx.p, ty.p, xf.p, yf.p, σ, dx, dy, nx, ny, Nf))
+"advect_front! + move_front! code3_fun.jl:144-195"
+advect_move_front!(c, uf, vf, xf, yf, u, v, dx, dy, dt, Lx, Ly, nx, ny, Nf) =
+    check(ccall((:nsk_bub_advect_move_front, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint, Ptr{Cint}),
+        c.h, uf.p, vf.p, xf.p, yf.p, u.p, v.p, dx, dy, dt, Lx, Ly, nx, ny, Nf, Ptr{Cint}(C_NULL)))
+"fx = fy = 0; distribute! code3_fun.jl:433-435,197-222"
+distribute!(c, fx, fy, xf, yf, ρ₁, ρ₂, dx, dy, nx, ny, Nf) =
+    check(ccall((:nsk_bub_distribute, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, PD, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Cint),
+        c.h, fx.p, fy.p, xf.p, yf.p, ρ₁, ρ₂, dx, dy, nx, ny, Nf))
+function construct_den!(c, r, fx, fy, β, maxit, maxError, dx, dy, nx, ny)
+    sw = Ref{Cint}(0)
+    check(ccall((:nsk_bub_construct_den, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, Cdouble, Cint, Cdouble, Cdouble, Cdouble, Cint, Cint, Ptr{Cint}),
+        c.h, r.p, fx.p, fy.p, β, maxit, maxError, dx, dy, nx, ny, sw))
+    sw[]
+end
+update_visco!(c, r, m, m₁, m₂, ρ₁, ρ₂, nx, ny) =
+    check(ccall((:nsk_bub_update_visco, lib), Cint, (Ptr{Cvoid}, PD, PD, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint),
+        c.h, r.p, m.p, m₁, m₂, ρ₁, ρ₂, nx, ny))
+"a = 0.5*(a + b) on the first n values, code3_fun.jl:445-450"
+average!(c, a, b, n) =
+    check(ccall((:nsk_bub_average, lib), Cint, (Ptr{Cvoid}, PD, PD, Csize_t), c.h, a.p, b.p, n))
+"Front regridding code3_fun.jl:455-494; returns the new Nf."
+function regrid_front!(c, xf, yf, xs, ys, dx, dy, Nf, cap)
+    r = Ref{Cint}(0)
+    check(ccall((:nsk_bub_regrid_front, lib), Cint, (Ptr{Cvoid}, PD, PD, PD, PD, Cdouble, Cdouble, Cint, Cint, Ptr{Cint}),
+        c.h, xf.p, yf.p, xs.p, ys.p, dx, dy, Nf, cap, r))
+    r[]
+end
+
 end # module

@@ -1,21 +1,26 @@
-# Driver with the reference's surface, `runme(; n, do_vis, do_save)`, on top of libnsk.
-# NOT RUN here (no Julia in the build image).  Scalars follow scripts/NavierStokes_Re6.jl:14-56.
+# Drivers with the reference's surface, `runme(; n, do_vis, do_save)`, on top of libnsk.
+# NOT RUN here (no Julia in the build image).  `script = :NavierStokes` takes the scalars of
+# scripts/NavierStokes.jl:14-56 (153 x 255, Re = 1e4, no `n`), `script = :NavierStokes_Re6` those
+# of scripts/NavierStokes_Re6.jl:14-56 (nx = 160n-1, ny = 256n-1, Re = 1e6).
 include("NSK.jl")
 using .NSK, MAT, Printf
 
-function scalars(n; Re=1e6)
+function scalars(script::Symbol, n)
+    re6 = script == :NavierStokes_Re6
     ly, ρ, vin = 1.0, 1.0, 1.0
+    Re = re6 ? 1e6 : 1e4
     lx = 0.6ly; μ = 1/Re*ρ*vin*ly
-    ny, nx = n*256-1, n*160-1
+    ny = re6 ? n*256-1 : 255
+    nx = re6 ? n*160-1 : ceil(Int, ny*0.6)
     dx, dy = lx/nx, ly/ny
     dt = min(1/4.1*dy^2*ρ/μ, 1.0*dy/vin)
     (; nx, ny, lx, ly, ρ, vin, μ, dx, dy, dt, psc=ρ*vin^2, g=0.0, a2=(0.05ly)^2, b2=(0.05ly)^2,
-       ox=0.05ly, oy=-0.4ly, sinβ=0.0, cosβ=1.0, εit=1e-3, niter=50nx, nchk=4(nx-1),
-       damp=2/ny, dτ=0.9/sqrt(2)*dy, nt=10000, nsave=50)
+       ox=0.05ly, oy=-0.4ly, sinβ=0.0, cosβ=1.0, εit=1e-3, niter=50nx, nchk=(re6 ? 4 : 1)*(nx-1),
+       damp=2/ny, dτ=0.9/sqrt(2)*dy, nt=(re6 ? 10000 : 2000), nsave=(re6 ? 50 : 10))
 end
 
-function runme(; n=1, do_vis=true, do_save=false)
-    q = scalars(n); nx, ny = q.nx, q.ny
+function runme(; n=1, do_vis=true, do_save=false, script::Symbol=:NavierStokes_Re6)
+    q = scalars(script, n); nx, ny = q.nx, q.ny
     c = NSK.Ctx(0)
     z(a, b) = NSK.zeros(c, a, b)
     Pr, dPrdτ, C, C_o = z(nx,ny), z(nx-2,ny-2), z(nx,ny), z(nx,ny)
@@ -40,4 +45,8 @@ function runme(; n=1, do_vis=true, do_save=false)
     NSK.destroy(c)
 end
 
-runme(; n=16, do_vis=false, do_save=true)
+# scripts/NavierStokes_Re6.jl:252 ends with  runme(; n=16, do_vis=false, do_save=true);
+# scripts/NavierStokes.jl:252 with           runme(; do_vis=true, do_save=false)  ->  script=:NavierStokes
+if abspath(PROGRAM_FILE) == @__FILE__
+    runme(; n=16, do_vis=false, do_save=true)
+end
