@@ -226,6 +226,55 @@ int nsk_ns_step(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_params *p,
                 int *iters_out, double *err_hist, int *iter_hist, int hist_cap,
                 int *nhist_out);
 
+/* ---- slab decomposition of the Poisson loop over several GPUs ----------------------------------
+ * The reference is single-device; scripts/DNS.jl:65 (`@hide_communication`) is its only trace of
+ * a multi-device intent.  These entry points run NavierStokes.jl:84-95 on a global nx x (world *
+ * ny_loc) grid cut along iy into `world` slabs.  A group holds the slabs of one process:
+ * first_rank .. first_rank + nlocal - 1, slab i on HIP device devices[i] (all slabs: one host
+ * thread drives every GPU; one slab: one process per GPU).  The library owns the three pitched
+ * window arrays of each slab (Pr, dPrdtau on the Pr layout, divV; nsk_slabs_fields hands out the
+ * device pointers, nsk_slabs_window the geometry).  Between two exchanges a slab runs `halo` passes
+ * on its window of ny_loc + 2*halo rows; results equal the single-domain loop bit for bit.
+ * transport: 0 = automatic (device copies when nlocal == world, else RCCL), 1 = RCCL (ncclSend /
+ * ncclRecv in one ncclGroup per exchange on a communication stream per slab, ncclAllReduce(max) of
+ * the residual's bit pattern; librccl is loaded at run time), 2 = peer-to-peer device copies
+ * (needs nlocal == world).  unique_id: the 128 bytes of nsk_rccl_unique_id from ONE process,
+ * passed to all (NULL when nlocal == world).  No call blocks the host except upload, download,
+ * residual, poisson and sync. */
+typedef struct nsk_slabs nsk_slabs;
+int nsk_rccl_unique_id(void *id128);
+int nsk_slabs_create(int world, int first_rank, int nlocal, const int *devices,
+                     const nsk_ns_params *global, int ny_loc, int halo, int transport,
+                     const void *unique_id, nsk_slabs **out);
+int nsk_slabs_destroy(nsk_slabs *g);
+/* Geometry of local slab `local` (any output may be NULL): global rank, device, global 0-based row
+ * of the window's first row, window rows, owned window rows [own_lo, own_hi) 0-based, leading
+ * dimension of the three arrays. */
+int nsk_slabs_window(nsk_slabs *g, int local, int *rank, int *device, int *iy0, int *ny_win,
+                     int *own_lo, int *own_hi, int *ld);
+int nsk_slabs_fields(nsk_slabs *g, int local, double **Pr, double **dPrdtau, double **divV);
+/* Scatter / gather of GLOBAL host arrays in the reference's layout: field 0 = Pr (nx x nyg),
+ * 1 = dPrdtau ((nx-2) x (nyg-2)), 2 = divV (nx x nyg).  Upload fills each local window including
+ * its halo rows; download writes only the rows the local slabs own.  Synchronous. */
+int nsk_slabs_upload(nsk_slabs *g, int field, const double *host_global);
+int nsk_slabs_download(nsk_slabs *g, int field, double *host_global);
+/* Refresh the halo rows of the fields in field_mask (bit 0 Pr, bit 1 dPrdtau, bit 2 divV). */
+int nsk_slabs_exchange(nsk_slabs *g, int field_mask);
+/* `count` passes of NavierStokes.jl:85-87 on every local slab with an exchange of Pr and dPrdtau
+ * after every `halo` passes (and after the last). */
+int nsk_slabs_poisson_iters(nsk_slabs *g, int count);
+/* max|Rp| of NavierStokes.jl:89-90 over the whole grid (identical in every process). */
+int nsk_slabs_residual(nsk_slabs *g, double *maxabs_out);
+/* The loop NavierStokes.jl:84-95 (niter, nchk, eps_it, ly, psc of the global parameter block);
+ * outputs as nsk_ns_poisson. */
+int nsk_slabs_poisson(nsk_slabs *g, int *iters_out, double *err_hist, int *iter_hist,
+                      int hist_cap, int *nhist_out);
+int nsk_slabs_sync(nsk_slabs *g);
+/* Transport check that needs no second GPU (RCCL groups only): every local slab sends the first
+ * `rows` owned rows of Pr to itself and receives them into the first `rows` owned rows of divV. */
+int nsk_slabs_rccl_self_exchange(nsk_slabs *g, int rows);
+int nsk_slabs_info(nsk_slabs *g, int *world, int *nlocal, int *transport, int *exchanges);
+
 /* ---- bubble / drop solvers: scripts/DNS.jl (= scripts/code1.m) and scripts/code3_fun.jl ---
  * Grid arrays are (nx+2) x (ny+2) with one ghost layer; u is (nx+1) x (ny+2), v is
  * (nx+2) x (ny+1); fronts are vectors with points 2..Nf+1 and two periodic ghost points

@@ -167,6 +167,69 @@ function division_form(d)
     f[], rh[], rl[]
 end
 
+# ---- slab decomposition over several GPUs (one Julia process drives all of them) -------------
+struct Slabs
+    h::Ptr{Cvoid}
+    nlocal::Int
+end
+function rccl_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(ccall((:nsk_rccl_unique_id, lib), Cint, (Ptr{Cvoid},), id))
+    id
+end
+"All `world` slabs in this process on `devices` (transport 0: device copies; 1: RCCL)."
+function Slabs(devices::Vector{<:Integer}, p::Params, ny_loc, halo; world=length(devices), first_rank=0, transport=0,
+               unique_id=C_NULL)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    dev = Vector{Cint}(devices)
+    check(ccall((:nsk_slabs_create, lib), Cint,
+        (Cint, Cint, Cint, Ptr{Cint}, Ref{Params}, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}),
+        world, first_rank, length(dev), dev, p, ny_loc, halo, transport, unique_id, r))
+    Slabs(r[], length(dev))
+end
+destroy(s::Slabs) = ccall((:nsk_slabs_destroy, lib), Cint, (Ptr{Cvoid},), s.h)
+function window(s::Slabs, local_)
+    v = [Ref{Cint}(0) for _ = 1:7]
+    check(ccall((:nsk_slabs_window, lib), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}),
+        s.h, local_, v[1], v[2], v[3], v[4], v[5], v[6], v[7]))
+    (; rank=v[1][], device=v[2][], iy0=v[3][], ny_win=v[4][], own_lo=v[5][], own_hi=v[6][], ld=v[7][])
+end
+function fields(s::Slabs, local_)
+    a = Ref{Ptr{Cdouble}}(C_NULL); b = Ref{Ptr{Cdouble}}(C_NULL); d = Ref{Ptr{Cdouble}}(C_NULL)
+    check(ccall((:nsk_slabs_fields, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Ptr{Cdouble}}, Ptr{Ptr{Cdouble}}, Ptr{Ptr{Cdouble}}),
+        s.h, local_, a, b, d))
+    a[], b[], d[]
+end
+"field: 0 Pr (nx x nyg), 1 dPrdτ ((nx-2) x (nyg-2)), 2 ∇V -- global host arrays"
+upload!(s::Slabs, field, a::Array{Float64}) =
+    check(ccall((:nsk_slabs_upload, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}), s.h, field, a))
+download!(s::Slabs, field, a::Array{Float64}) =
+    check(ccall((:nsk_slabs_download, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}), s.h, field, a))
+exchange!(s::Slabs, mask=3) = check(ccall((:nsk_slabs_exchange, lib), Cint, (Ptr{Cvoid}, Cint), s.h, mask))
+poisson_iters!(s::Slabs, count) = check(ccall((:nsk_slabs_poisson_iters, lib), Cint, (Ptr{Cvoid}, Cint), s.h, count))
+function residual(s::Slabs)
+    r = Ref{Cdouble}(0.0)
+    check(ccall((:nsk_slabs_residual, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), s.h, r))
+    r[]
+end
+function poisson!(s::Slabs; cap=1024)
+    iters = Ref{Cint}(0); nh = Ref{Cint}(0)
+    errs = Vector{Cdouble}(undef, cap); its = Vector{Cint}(undef, cap)
+    check(ccall((:nsk_slabs_poisson, lib), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cint}, Cint, Ptr{Cint}),
+        s.h, iters, errs, its, cap, nh))
+    n = min(nh[], cap)
+    iters[], collect(zip(its[1:n], errs[1:n]))
+end
+sync(s::Slabs) = check(ccall((:nsk_slabs_sync, lib), Cint, (Ptr{Cvoid},), s.h))
+rccl_self_exchange!(s::Slabs, rows) =
+    check(ccall((:nsk_slabs_rccl_self_exchange, lib), Cint, (Ptr{Cvoid}, Cint), s.h, rows))
+function info(s::Slabs)
+    v = [Ref{Cint}(0) for _ = 1:4]
+    check(ccall((:nsk_slabs_info, lib), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}), s.h, v[1], v[2], v[3], v[4]))
+    (; world=v[1][], nlocal=v[2][], transport=v[3][], exchanges=v[4][])
+end
+
 # ---- bubble / drop solvers: scripts/DNS.jl (in the form scripts/code1.m states) and ----------
 # ---- scripts/code3_fun.jl; one stub per kernel, argument order of the Julia kernels ----------
 vec(c::Ctx, n) = zeros(c, n, 1)

@@ -96,6 +96,22 @@ _SIGS = {
     "nsk_ns_step": [C.POINTER(CNSState), C.POINTER(CNSParams), c_int_p, c_double_p, c_int_p, _I, c_int_p],
 }
 
+# slab-group entry points (after the leading group pointer)
+_SLAB_SIGS = {
+    "nsk_slabs_destroy": [],
+    "nsk_slabs_window": [_I] + [c_int_p] * 7,
+    "nsk_slabs_fields": [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)],
+    "nsk_slabs_upload": [_I, _P],
+    "nsk_slabs_download": [_I, _P],
+    "nsk_slabs_exchange": [_I],
+    "nsk_slabs_poisson_iters": [_I],
+    "nsk_slabs_residual": [c_double_p],
+    "nsk_slabs_poisson": [c_int_p, c_double_p, c_int_p, _I, c_int_p],
+    "nsk_slabs_sync": [],
+    "nsk_slabs_rccl_self_exchange": [_I],
+    "nsk_slabs_info": [c_int_p] * 4,
+}
+
 _lib = None
 
 
@@ -122,6 +138,14 @@ def load() -> C.CDLL:
     lib.nsk_poisson_plan.restype = _I
     lib.nsk_division_form.argtypes = [_D, c_int_p, c_double_p, c_double_p]
     lib.nsk_division_form.restype = _I
+    lib.nsk_rccl_unique_id.argtypes = [_P]
+    lib.nsk_rccl_unique_id.restype = _I
+    lib.nsk_slabs_create.argtypes = [_I, _I, _I, c_int_p, C.POINTER(CNSParams), _I, _I, _I, _P, C.POINTER(_P)]
+    lib.nsk_slabs_create.restype = _I
+    for name, args in _SLAB_SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [_P] + args
+        fn.restype = _I
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = [_P] + args
@@ -144,7 +168,7 @@ def poisson_kernel_hash() -> str:
 
 def exported_names() -> list[str]:
     return ["nsk_create", "nsk_destroy", "nsk_last_error", "nsk_version", "nsk_poisson_plan",
-            "nsk_division_form"] + list(_SIGS)
+            "nsk_division_form", "nsk_rccl_unique_id", "nsk_slabs_create"] + list(_SIGS) + list(_SLAB_SIGS)
 
 
 def poisson_plan(nx: int, ny: int, num_simds: int = 1024, staged: bool = True, k: int = 0, k_limit: int = 8,
@@ -164,6 +188,89 @@ def division_form(d: float) -> tuple[int, float, float]:
     if lib.nsk_division_form(float(d), C.byref(form), C.byref(rh), C.byref(rl)) != 0:
         raise NskError(lib.nsk_last_error().decode())
     return form.value, rh.value, rl.value
+
+
+def rccl_unique_id() -> bytes:
+    """nsk_rccl_unique_id: 128 bytes to hand to every process of a slab group."""
+    buf = C.create_string_buffer(128)
+    lib = load()
+    if lib.nsk_rccl_unique_id(buf) != 0:
+        raise NskError(lib.nsk_last_error().decode())
+    return buf.raw
+
+
+class Slabs:
+    """nsk_slabs: the slabs of this process (include/nsk.h).  transport: 0 auto, 1 RCCL, 2 device copies."""
+
+    FIELDS = {"Pr": 0, "dPrdtau": 1, "divV": 2}
+
+    def __init__(self, world, first_rank, devices, cparams: CNSParams, ny_loc, halo, transport=0, unique_id=None):
+        self.lib = load()
+        h = _P()
+        dev = (C.c_int * len(devices))(*devices)
+        uid = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        rc = self.lib.nsk_slabs_create(world, first_rank, len(devices), dev, C.byref(cparams), ny_loc, halo, transport,
+                                       uid, C.byref(h))
+        if rc != 0:
+            raise NskError(self.lib.nsk_last_error().decode())
+        self.handle, self.nlocal = h, len(devices)
+
+    def call(self, name, *args):
+        if getattr(self.lib, name)(self.handle, *args) != 0:
+            raise NskError(f"{name}: {self.lib.nsk_last_error().decode()}")
+
+    def window(self, local=0) -> dict:
+        v = [C.c_int(0) for _ in range(7)]
+        self.call("nsk_slabs_window", local, *[C.byref(x) for x in v])
+        return dict(zip(("rank", "device", "iy0", "ny_win", "own_lo", "own_hi", "ld"), (x.value for x in v)))
+
+    def fields(self, local=0) -> dict:
+        p = [_P() for _ in range(3)]
+        self.call("nsk_slabs_fields", local, *[C.byref(x) for x in p])
+        return dict(zip(("Pr", "dPrdtau", "divV"), (x.value for x in p)))
+
+    def upload(self, field: str, host) -> None:
+        self.call("nsk_slabs_upload", self.FIELDS[field], host.ctypes.data_as(_P))
+
+    def download(self, field: str, host) -> None:
+        self.call("nsk_slabs_download", self.FIELDS[field], host.ctypes.data_as(_P))
+
+    def exchange(self, mask=3) -> None:
+        self.call("nsk_slabs_exchange", mask)
+
+    def poisson_iters(self, count) -> None:
+        self.call("nsk_slabs_poisson_iters", int(count))
+
+    def residual(self) -> float:
+        m = C.c_double(0.0)
+        self.call("nsk_slabs_residual", C.byref(m))
+        return m.value
+
+    def poisson(self, cap=1024):
+        iters, nh = C.c_int(0), C.c_int(0)
+        he, hi = (C.c_double * cap)(), (C.c_int * cap)()
+        self.call("nsk_slabs_poisson", C.byref(iters), he, hi, cap, C.byref(nh))
+        n = min(nh.value, cap)
+        return iters.value, list(hi[:n]), list(he[:n])
+
+    def sync(self) -> None:
+        self.call("nsk_slabs_sync")
+
+    def info(self) -> dict:
+        v = [C.c_int(0) for _ in range(4)]
+        self.call("nsk_slabs_info", *[C.byref(x) for x in v])
+        return dict(zip(("world", "nlocal", "transport", "exchanges"), (x.value for x in v)))
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.nsk_slabs_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

@@ -1,0 +1,547 @@
+// Slab decomposition of the pressure-Poisson loop behind the C ABI (nsk_slabs_*).
+//
+// The reference is single-device (no MPI / NCCL anywhere in it); this is the multi-GPU form of its
+// loop scripts/NavierStokes.jl:84-95.  The global grid (nx x nyg) is cut along iy into `world`
+// slabs of ny_loc rows; slab g holds its rows plus `halo` rows per interior side.  One pass moves
+// information by one row, so a window with `halo` valid halo rows runs `halo` passes between two
+// exchanges of `halo` rows of Pr and dPrdτ (bit-identical to the single domain: every owned cell
+// is computed by the same expression from the same inputs).
+//
+// A group object holds the slabs of ONE process: all of them (a single host thread drives every
+// GPU of the node, the natural shape for a Julia driver) or one (one process per GPU).  Halo rows
+// travel either through RCCL (ncclSend / ncclRecv of whole row blocks inside one ncclGroup per
+// exchange, ncclAllReduce(max) of the residual's bit pattern) or, when every slab lives in this
+// process, through peer-to-peer device copies on the slabs' communication streams.  RCCL is
+// loaded at run time (dlopen), so a single-GPU user of the library does not depend on it.
+//
+// Streams: each slab's kernels run on its context's stream; transfers run on a second stream per
+// slab, ordered against the kernels with events, never with host waits -- the host thread only
+// queues work, so the slabs of a group run concurrently.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <vector>
+
+#include "nsk_internal.h"
+
+namespace {
+
+// ---- RCCL entry points, resolved on first use ---------------------------------------------------
+struct Rccl {
+  void *handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool ok = false;
+};
+
+Rccl *rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r.ok ? &r : nullptr;
+  tried = true;
+  // a copy already mapped into the process (a host framework's) is found first by its soname
+  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (r.handle) break;
+  }
+  if (!r.handle) return nullptr;
+#define NSK_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, sym))
+  NSK_SYM(GetUniqueId, "ncclGetUniqueId");
+  NSK_SYM(CommInitRank, "ncclCommInitRank");
+  NSK_SYM(CommDestroy, "ncclCommDestroy");
+  NSK_SYM(GroupStart, "ncclGroupStart");
+  NSK_SYM(GroupEnd, "ncclGroupEnd");
+  NSK_SYM(Send, "ncclSend");
+  NSK_SYM(Recv, "ncclRecv");
+  NSK_SYM(AllReduce, "ncclAllReduce");
+  NSK_SYM(GetErrorString, "ncclGetErrorString");
+#undef NSK_SYM
+  r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv &&
+         r.AllReduce && r.GetErrorString;
+  return r.ok ? &r : nullptr;
+}
+
+#define NSK_NCCL(call)                                                                              \
+  do {                                                                                              \
+    ncclResult_t r_ = (call);                                                                       \
+    if (r_ != ncclSuccess) {                                                                        \
+      nsk_set_error("%s failed: %s (%s:%d)", #call, rccl()->GetErrorString(r_), __FILE__, __LINE__); \
+      return 1;                                                                                     \
+    }                                                                                               \
+  } while (0)
+
+enum { TRANSPORT_AUTO = 0, TRANSPORT_RCCL = 1, TRANSPORT_COPY = 2 };
+
+struct Slab {
+  int rank = 0, device = 0;
+  int lo_halo = 0, hi_halo = 0, iy0 = 0, ny_win = 0, own_lo = 0, own_hi = 0;  // 0-based window rows, own_hi exclusive
+  nsk_ctx *ctx = nullptr;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_done = nullptr, ev_comm = nullptr;
+  double *Pr = nullptr, *dP = nullptr, *divV = nullptr;  // (ny_win x ld), dPrdτ on the Pr layout
+  unsigned long long *red = nullptr;                     // one word for the all-reduce
+  ncclComm_t comm = nullptr;
+  nsk_ns_params prm{};
+};
+
+}  // namespace
+
+struct nsk_slabs {
+  int world = 1, first = 0, nlocal = 1, ny_loc = 0, halo = 0, ld = 0, transport = TRANSPORT_COPY;
+  nsk_ns_params global{};
+  std::vector<Slab> slabs;
+  unsigned long long *red_host = nullptr;  // pinned
+  int exchanges = 0;
+};
+
+namespace {
+
+inline int pitch_of(int nx) { return (nx + 1 + 15) / 16 * 16; }
+
+// Refresh the halo rows of fields `which` (bit 0 Pr, bit 1 dPrdτ, bit 2 ∇V) of every local slab.
+int exchange_fields(nsk_slabs *g, int which) {
+  if (g->world == 1 || which == 0) return 0;
+  const size_t ld = (size_t)g->ld;
+  const int h = g->halo;
+  const size_t count = (size_t)h * ld;
+  auto field = [&](Slab &s, int f) { return f == 0 ? s.Pr : f == 1 ? s.dP : s.divV; };
+  for (Slab &s : g->slabs) {  // transfers start when the slab's kernels are done
+    NSK_HIP(hipSetDevice(s.device));
+    NSK_HIP(hipEventRecord(s.ev_done, s.ctx->stream));
+  }
+  if (g->transport == TRANSPORT_RCCL) {
+    Rccl *R = rccl();
+    for (Slab &s : g->slabs) {
+      NSK_HIP(hipSetDevice(s.device));
+      NSK_HIP(hipStreamWaitEvent(s.comm_stream, s.ev_done, 0));
+    }
+    NSK_NCCL(R->GroupStart());
+    for (Slab &s : g->slabs) {
+      NSK_HIP(hipSetDevice(s.device));
+      for (int f = 0; f < 3; f++) {
+        if (!(which & (1 << f))) continue;
+        double *a = field(s, f);
+        if (s.rank > 0) {  // lower neighbour: my first owned rows go down, its last owned rows come up
+          NSK_NCCL(R->Send(a + (size_t)s.own_lo * ld, count, ncclDouble, s.rank - 1, s.comm, s.comm_stream));
+          NSK_NCCL(R->Recv(a + (size_t)(s.own_lo - h) * ld, count, ncclDouble, s.rank - 1, s.comm, s.comm_stream));
+        }
+        if (s.rank < g->world - 1) {
+          NSK_NCCL(R->Send(a + (size_t)(s.own_hi - h) * ld, count, ncclDouble, s.rank + 1, s.comm, s.comm_stream));
+          NSK_NCCL(R->Recv(a + (size_t)s.own_hi * ld, count, ncclDouble, s.rank + 1, s.comm, s.comm_stream));
+        }
+      }
+    }
+    NSK_NCCL(R->GroupEnd());
+    for (Slab &s : g->slabs) {
+      NSK_HIP(hipSetDevice(s.device));
+      NSK_HIP(hipEventRecord(s.ev_comm, s.comm_stream));
+      NSK_HIP(hipStreamWaitEvent(s.ctx->stream, s.ev_comm, 0));
+    }
+  } else {
+    // Every slab pulls its halo rows from its neighbours' owned rows on its own communication
+    // stream, once its own kernels (which still read and write the halo rows) and the
+    // neighbour's (which produce the rows) are done.
+    const int n = (int)g->slabs.size();
+    for (int i = 0; i < n; i++) {
+      Slab &s = g->slabs[i];
+      NSK_HIP(hipSetDevice(s.device));
+      NSK_HIP(hipStreamWaitEvent(s.comm_stream, s.ev_done, 0));
+      if (i > 0) NSK_HIP(hipStreamWaitEvent(s.comm_stream, g->slabs[i - 1].ev_done, 0));
+      if (i < n - 1) NSK_HIP(hipStreamWaitEvent(s.comm_stream, g->slabs[i + 1].ev_done, 0));
+      for (int f = 0; f < 3; f++) {
+        if (!(which & (1 << f))) continue;
+        double *a = field(s, f);
+        if (i > 0) {
+          Slab &lo = g->slabs[i - 1];
+          const double *src = field(lo, f) + (size_t)(lo.own_hi - h) * ld;
+          double *dst = a + (size_t)(s.own_lo - h) * ld;
+          if (lo.device == s.device)
+            NSK_HIP(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, s.comm_stream));
+          else
+            NSK_HIP(hipMemcpyPeerAsync(dst, s.device, src, lo.device, count * sizeof(double), s.comm_stream));
+        }
+        if (i < n - 1) {
+          Slab &hi = g->slabs[i + 1];
+          const double *src = field(hi, f) + (size_t)hi.own_lo * ld;
+          double *dst = a + (size_t)s.own_hi * ld;
+          if (hi.device == s.device)
+            NSK_HIP(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, s.comm_stream));
+          else
+            NSK_HIP(hipMemcpyPeerAsync(dst, s.device, src, hi.device, count * sizeof(double), s.comm_stream));
+        }
+      }
+      NSK_HIP(hipEventRecord(s.ev_comm, s.comm_stream));
+    }
+    // a slab's kernels go on when its halo rows have arrived and its neighbours have read its rows
+    for (int i = 0; i < n; i++) {
+      Slab &s = g->slabs[i];
+      NSK_HIP(hipSetDevice(s.device));
+      NSK_HIP(hipStreamWaitEvent(s.ctx->stream, s.ev_comm, 0));
+      if (i > 0) NSK_HIP(hipStreamWaitEvent(s.ctx->stream, g->slabs[i - 1].ev_comm, 0));
+      if (i < n - 1) NSK_HIP(hipStreamWaitEvent(s.ctx->stream, g->slabs[i + 1].ev_comm, 0));
+    }
+  }
+  g->exchanges++;
+  return 0;
+}
+
+void release(nsk_slabs *g) {
+  for (Slab &s : g->slabs) {
+    (void)hipSetDevice(s.device);
+    if (s.ctx) (void)hipStreamSynchronize(s.ctx->stream);
+    if (s.comm_stream) (void)hipStreamSynchronize(s.comm_stream);
+    if (s.comm && rccl()) (void)rccl()->CommDestroy(s.comm);
+    for (double *p : {s.Pr, s.dP, s.divV})
+      if (p) (void)hipFree(p);
+    if (s.red) (void)hipFree(s.red);
+    if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+    if (s.ev_comm) (void)hipEventDestroy(s.ev_comm);
+    if (s.comm_stream) (void)hipStreamDestroy(s.comm_stream);
+    if (s.ctx) (void)nsk_destroy(s.ctx);
+  }
+  if (g->red_host) (void)hipHostFree(g->red_host);
+  delete g;
+}
+
+#define NSK_GROUP(g, local)                                         \
+  NSK_REQUIRE((g) != nullptr, "null slab group");                   \
+  NSK_REQUIRE((local) >= 0 && (local) < (g)->nlocal, "local slab index %d outside 0..%d", (local), (g)->nlocal - 1)
+
+}  // namespace
+
+extern "C" int nsk_rccl_unique_id(void *id128) {
+  NSK_REQUIRE(id128 != nullptr, "nsk_rccl_unique_id: null buffer");
+  Rccl *R = rccl();
+  NSK_REQUIRE(R != nullptr, "RCCL could not be loaded (librccl.so.1): %s", dlerror() ? dlerror() : "symbols missing");
+  static_assert(sizeof(ncclUniqueId) == 128, "the ABI documents a 128-byte id");
+  ncclUniqueId id;
+  NSK_NCCL(R->GetUniqueId(&id));
+  memcpy(id128, &id, sizeof id);
+  return 0;
+}
+
+extern "C" int nsk_slabs_create(int world, int first_rank, int nlocal, const int *devices,
+                                const nsk_ns_params *global, int ny_loc, int halo, int transport,
+                                const void *unique_id, nsk_slabs **out) {
+  NSK_REQUIRE(out != nullptr, "nsk_slabs_create: out is null");
+  *out = nullptr;
+  NSK_REQUIRE(global != nullptr && devices != nullptr, "nsk_slabs_create: null argument");
+  NSK_REQUIRE(world >= 1 && nlocal >= 1 && first_rank >= 0 && first_rank + nlocal <= world,
+              "slabs %d..%d outside a world of %d", first_rank, first_rank + nlocal - 1, world);
+  NSK_REQUIRE(global->nx >= 3 && ny_loc >= 3 && global->ny == ny_loc * world,
+              "global grid has %d rows, %d slabs of %d rows were asked for", global->ny, world, ny_loc);
+  if (world == 1) halo = 0;
+  NSK_REQUIRE(world == 1 || (halo >= 1 && halo <= ny_loc), "halo %d must be 1..%d rows", halo, ny_loc);
+  if (transport == TRANSPORT_AUTO) transport = nlocal == world ? TRANSPORT_COPY : TRANSPORT_RCCL;
+  NSK_REQUIRE(transport == TRANSPORT_RCCL || transport == TRANSPORT_COPY, "unknown transport %d", transport);
+  NSK_REQUIRE(transport == TRANSPORT_RCCL || nlocal == world,
+              "device copies need every slab in this process (%d of %d are)", nlocal, world);
+  ncclUniqueId id;
+  if (transport == TRANSPORT_RCCL) {
+    NSK_REQUIRE(rccl() != nullptr, "RCCL could not be loaded (librccl.so.1)");
+    if (unique_id) {
+      memcpy(&id, unique_id, sizeof id);
+    } else {
+      NSK_REQUIRE(nlocal == world, "slabs in several processes need the id of nsk_rccl_unique_id from one of them");
+      NSK_NCCL(rccl()->GetUniqueId(&id));
+    }
+  }
+  nsk_slabs *g = new nsk_slabs();
+  g->world = world;
+  g->first = first_rank;
+  g->nlocal = nlocal;
+  g->ny_loc = ny_loc;
+  g->halo = halo;
+  g->ld = pitch_of(global->nx);
+  g->transport = transport;
+  g->global = *global;
+  g->slabs.resize(nlocal);
+#define NSK_FAIL_IF(cond, ...)  \
+  do {                          \
+    if (cond) {                 \
+      nsk_set_error(__VA_ARGS__); \
+      release(g);               \
+      return 1;                 \
+    }                           \
+  } while (0)
+  NSK_FAIL_IF(hipHostMalloc(&g->red_host, 64, hipHostMallocDefault) != hipSuccess, "pinned allocation failed");
+  for (int i = 0; i < nlocal; i++) {
+    Slab &s = g->slabs[i];
+    s.rank = first_rank + i;
+    s.device = devices[i];
+    s.lo_halo = s.rank > 0 ? halo : 0;
+    s.hi_halo = s.rank < world - 1 ? halo : 0;
+    s.iy0 = s.rank * ny_loc - s.lo_halo;
+    s.ny_win = ny_loc + s.lo_halo + s.hi_halo;
+    s.own_lo = s.lo_halo;
+    s.own_hi = s.lo_halo + ny_loc;
+    s.prm = *global;
+    s.prm.ny = s.ny_win;
+    s.prm.iy0 = s.iy0;
+    s.prm.nyg = ny_loc * world;
+    s.prm.ld_pr = g->ld;
+    s.prm.ld_dp = 0;
+    s.prm.dp_embedded = 1;
+    NSK_FAIL_IF(nsk_create(s.device, &s.ctx) != 0, "slab %d: %s", s.rank, nsk_last_error());
+    const size_t bytes = (size_t)s.ny_win * g->ld * sizeof(double);
+    bool ok = hipStreamCreateWithFlags(&s.comm_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&s.ev_comm, hipEventDisableTiming) == hipSuccess &&
+              hipMalloc(&s.red, 64) == hipSuccess;
+    for (double **p : {&s.Pr, &s.dP, &s.divV})
+      ok = ok && hipMalloc(p, bytes) == hipSuccess && hipMemsetAsync(*p, 0, bytes, s.ctx->stream) == hipSuccess;
+    NSK_FAIL_IF(!ok, "slab %d: stream, event or %zu-byte field allocation failed", s.rank, bytes);
+  }
+  if (transport == TRANSPORT_COPY) {
+    for (int i = 0; i + 1 < nlocal; i++) {  // neighbours on different devices copy peer to peer
+      const int a = g->slabs[i].device, b = g->slabs[i + 1].device;
+      if (a == b) continue;
+      int can = 0;
+      NSK_FAIL_IF(hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can, "devices %d and %d cannot access each other", a, b);
+      for (int k = 0; k < 2; k++) {
+        (void)hipSetDevice(k ? b : a);
+        hipError_t e = hipDeviceEnablePeerAccess(k ? a : b, 0);
+        NSK_FAIL_IF(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled, "enabling peer access %d <-> %d failed", a, b);
+      }
+    }
+    (void)hipGetLastError();
+  } else {
+    Rccl *R = rccl();
+    bool ok = R->GroupStart() == ncclSuccess;
+    for (Slab &s : g->slabs) {
+      ok = ok && hipSetDevice(s.device) == hipSuccess;
+      ok = ok && R->CommInitRank(&s.comm, world, id, s.rank) == ncclSuccess;
+    }
+    ok = (R->GroupEnd() == ncclSuccess) && ok;
+    NSK_FAIL_IF(!ok, "RCCL communicator set-up failed for slabs %d..%d of %d", first_rank, first_rank + nlocal - 1, world);
+  }
+#undef NSK_FAIL_IF
+  *out = g;
+  return 0;
+}
+
+extern "C" int nsk_slabs_destroy(nsk_slabs *g) {
+  if (g) release(g);
+  return 0;
+}
+
+extern "C" int nsk_slabs_window(nsk_slabs *g, int local, int *rank, int *device, int *iy0, int *ny_win,
+                                int *own_lo, int *own_hi, int *ld) {
+  NSK_GROUP(g, local);
+  const Slab &s = g->slabs[local];
+  if (rank) *rank = s.rank;
+  if (device) *device = s.device;
+  if (iy0) *iy0 = s.iy0;
+  if (ny_win) *ny_win = s.ny_win;
+  if (own_lo) *own_lo = s.own_lo;
+  if (own_hi) *own_hi = s.own_hi;
+  if (ld) *ld = g->ld;
+  return 0;
+}
+
+extern "C" int nsk_slabs_fields(nsk_slabs *g, int local, double **Pr, double **dPrdtau, double **divV) {
+  NSK_GROUP(g, local);
+  const Slab &s = g->slabs[local];
+  if (Pr) *Pr = s.Pr;
+  if (dPrdtau) *dPrdtau = s.dP;
+  if (divV) *divV = s.divV;
+  return 0;
+}
+
+// field: 0 Pr (nx x nyg), 1 dPrdτ ((nx-2) x (nyg-2), the reference's array), 2 ∇V (nx x nyg)
+extern "C" int nsk_slabs_upload(nsk_slabs *g, int field, const double *host) {
+  NSK_GROUP(g, 0);
+  NSK_REQUIRE(host != nullptr && field >= 0 && field <= 2, "nsk_slabs_upload: bad arguments");
+  const int nx = g->global.nx, nyg = g->ny_loc * g->world;
+  const size_t w = sizeof(double);
+  for (Slab &s : g->slabs) {
+    NSK_HIP(hipSetDevice(s.device));
+    if (field == 1) {  // value of pressure cell (ix, iy) goes to the offset of that cell; the rim is unused
+      const int a = s.iy0 > 1 ? s.iy0 : 1, b = (s.iy0 + s.ny_win < nyg - 1) ? s.iy0 + s.ny_win : nyg - 1;  // Pr rows [a, b)
+      NSK_HIP(hipMemcpy2DAsync(s.dP + (size_t)(a - s.iy0) * g->ld + 1, g->ld * w, host + (size_t)(a - 1) * (nx - 2),
+                               (size_t)(nx - 2) * w, (size_t)(nx - 2) * w, b - a, hipMemcpyHostToDevice, s.ctx->stream));
+    } else {
+      double *dst = field == 0 ? s.Pr : s.divV;
+      NSK_HIP(hipMemcpy2DAsync(dst, g->ld * w, host + (size_t)s.iy0 * nx, (size_t)nx * w, (size_t)nx * w, s.ny_win,
+                               hipMemcpyHostToDevice, s.ctx->stream));
+    }
+  }
+  for (Slab &s : g->slabs) {
+    NSK_HIP(hipSetDevice(s.device));
+    NSK_HIP(hipStreamSynchronize(s.ctx->stream));
+  }
+  return 0;
+}
+
+// Writes the rows the local slabs own into the global host array (other rows are left alone).
+extern "C" int nsk_slabs_download(nsk_slabs *g, int field, double *host) {
+  NSK_GROUP(g, 0);
+  NSK_REQUIRE(host != nullptr && field >= 0 && field <= 2, "nsk_slabs_download: bad arguments");
+  const int nx = g->global.nx, nyg = g->ny_loc * g->world;
+  const size_t w = sizeof(double);
+  for (Slab &s : g->slabs) {
+    NSK_HIP(hipSetDevice(s.device));
+    const int g0 = s.iy0 + s.own_lo, g1 = s.iy0 + s.own_hi;  // global rows [g0, g1)
+    if (field == 1) {
+      const int a = g0 > 1 ? g0 : 1, b = g1 < nyg - 1 ? g1 : nyg - 1;
+      NSK_HIP(hipMemcpy2DAsync(host + (size_t)(a - 1) * (nx - 2), (size_t)(nx - 2) * w,
+                               s.dP + (size_t)(a - s.iy0) * g->ld + 1, g->ld * w, (size_t)(nx - 2) * w, b - a,
+                               hipMemcpyDeviceToHost, s.ctx->stream));
+    } else {
+      const double *src = field == 0 ? s.Pr : s.divV;
+      NSK_HIP(hipMemcpy2DAsync(host + (size_t)g0 * nx, (size_t)nx * w, src + (size_t)s.own_lo * g->ld, g->ld * w,
+                               (size_t)nx * w, g1 - g0, hipMemcpyDeviceToHost, s.ctx->stream));
+    }
+  }
+  for (Slab &s : g->slabs) {
+    NSK_HIP(hipSetDevice(s.device));
+    NSK_HIP(hipStreamSynchronize(s.ctx->stream));
+  }
+  return 0;
+}
+
+extern "C" int nsk_slabs_exchange(nsk_slabs *g, int field_mask) {
+  NSK_GROUP(g, 0);
+  NSK_REQUIRE(field_mask >= 0 && field_mask <= 7, "field mask %d outside 0..7", field_mask);
+  return exchange_fields(g, field_mask);
+}
+
+extern "C" int nsk_slabs_sync(nsk_slabs *g) {
+  NSK_GROUP(g, 0);
+  for (Slab &s : g->slabs) {
+    NSK_HIP(hipSetDevice(s.device));
+    NSK_HIP(hipStreamSynchronize(s.comm_stream));
+    NSK_HIP(hipStreamSynchronize(s.ctx->stream));
+  }
+  return 0;
+}
+
+extern "C" int nsk_slabs_poisson_iters(nsk_slabs *g, int count) {
+  NSK_GROUP(g, 0);
+  NSK_REQUIRE(count >= 0, "negative pass count %d", count);
+  int left = count;
+  while (left > 0) {
+    const int n = g->world == 1 ? left : (left < g->halo ? left : g->halo);
+    for (Slab &s : g->slabs)
+      if (int rc = nsk_ns_poisson_iters(s.ctx, s.Pr, s.dP, s.divV, &s.prm, n)) return rc;
+    if (int rc = exchange_fields(g, 3)) return rc;
+    left -= n;
+  }
+  return 0;
+}
+
+// max|Rp| over the whole grid (NavierStokes.jl:89-90): local maxima over owned rows, then the
+// maximum of the bit patterns (|x| >= 0, so the integer order is the IEEE order and NaN stays on top).
+extern "C" int nsk_slabs_residual(nsk_slabs *g, double *maxabs_out) {
+  NSK_GROUP(g, 0);
+  NSK_REQUIRE(maxabs_out != nullptr, "nsk_slabs_residual: maxabs_out is null");
+  unsigned long long m = 0;
+  for (Slab &s : g->slabs) {
+    double v = 0.0;
+    if (int rc = nsk_ns_residual(s.ctx, nullptr, s.Pr, s.divV, &s.prm, s.own_lo + 1, s.own_hi, &v)) return rc;
+    unsigned long long b;
+    v = std::fabs(v);
+    memcpy(&b, &v, sizeof b);
+    m = b > m ? b : m;
+  }
+  if (g->transport == TRANSPORT_RCCL) {  // (also with one slab: the reduction is then the identity)
+    Rccl *R = rccl();
+    g->red_host[0] = m;
+    for (Slab &s : g->slabs) {
+      NSK_HIP(hipSetDevice(s.device));
+      NSK_HIP(hipMemcpyAsync(s.red, g->red_host, sizeof m, hipMemcpyHostToDevice, s.comm_stream));
+    }
+    NSK_NCCL(R->GroupStart());
+    for (Slab &s : g->slabs) {
+      NSK_HIP(hipSetDevice(s.device));
+      NSK_NCCL(R->AllReduce(s.red, s.red, 1, ncclUint64, ncclMax, s.comm, s.comm_stream));
+    }
+    NSK_NCCL(R->GroupEnd());
+    Slab &s0 = g->slabs[0];
+    NSK_HIP(hipSetDevice(s0.device));
+    NSK_HIP(hipMemcpyAsync(g->red_host + 1, s0.red, sizeof m, hipMemcpyDeviceToHost, s0.comm_stream));
+    for (Slab &s : g->slabs) {
+      NSK_HIP(hipSetDevice(s.device));
+      NSK_HIP(hipStreamSynchronize(s.comm_stream));
+    }
+    m = g->red_host[1];
+  }
+  memcpy(maxabs_out, &m, sizeof m);
+  return 0;
+}
+
+// The Poisson loop NavierStokes.jl:84-95 on the slab-decomposed grid.
+extern "C" int nsk_slabs_poisson(nsk_slabs *g, int *iters_out, double *err_hist, int *iter_hist, int hist_cap,
+                                 int *nhist_out) {
+  NSK_GROUP(g, 0);
+  const nsk_ns_params *p = &g->global;
+  const int niter = p->niter, nchk = p->nchk;
+  int done = 0, nh = 0;
+  while (done < niter) {
+    int chunk = nchk > 0 ? nchk - (done % nchk) : niter - done;
+    if (chunk > niter - done) chunk = niter - done;
+    if (int rc = nsk_slabs_poisson_iters(g, chunk)) return rc;
+    done += chunk;
+    if (nchk > 0 && done % nchk == 0) {
+      double m = 0.0;
+      if (int rc = nsk_slabs_residual(g, &m)) return rc;
+      const double err = m * (p->ly * p->ly) / p->psc;  // NavierStokes.jl:90
+      if (nh < hist_cap) {
+        if (err_hist) err_hist[nh] = err;
+        if (iter_hist) iter_hist[nh] = done;
+      }
+      nh++;
+      if (err < p->eps_it || !std::isfinite(err)) break;  // :93
+    }
+  }
+  if (int rc = nsk_slabs_sync(g)) return rc;
+  if (iters_out) *iters_out = done;
+  if (nhist_out) *nhist_out = nh;
+  return 0;
+}
+
+// Transport check that needs no second GPU: every local slab sends the first `rows` owned rows of
+// Pr to ITSELF through RCCL and receives them into the first `rows` owned rows of divV, with the
+// same stream and event ordering as a halo exchange.
+extern "C" int nsk_slabs_rccl_self_exchange(nsk_slabs *g, int rows) {
+  NSK_GROUP(g, 0);
+  NSK_REQUIRE(g->transport == TRANSPORT_RCCL, "the group does not use RCCL");
+  NSK_REQUIRE(rows >= 1 && rows <= g->ny_loc, "rows %d outside 1..%d", rows, g->ny_loc);
+  Rccl *R = rccl();
+  const size_t ld = (size_t)g->ld, count = (size_t)rows * ld;
+  for (Slab &s : g->slabs) {
+    NSK_HIP(hipSetDevice(s.device));
+    NSK_HIP(hipEventRecord(s.ev_done, s.ctx->stream));
+    NSK_HIP(hipStreamWaitEvent(s.comm_stream, s.ev_done, 0));
+  }
+  NSK_NCCL(R->GroupStart());
+  for (Slab &s : g->slabs) {
+    NSK_HIP(hipSetDevice(s.device));
+    NSK_NCCL(R->Send(s.Pr + (size_t)s.own_lo * ld, count, ncclDouble, s.rank, s.comm, s.comm_stream));
+    NSK_NCCL(R->Recv(s.divV + (size_t)s.own_lo * ld, count, ncclDouble, s.rank, s.comm, s.comm_stream));
+  }
+  NSK_NCCL(R->GroupEnd());
+  for (Slab &s : g->slabs) {
+    NSK_HIP(hipSetDevice(s.device));
+    NSK_HIP(hipEventRecord(s.ev_comm, s.comm_stream));
+    NSK_HIP(hipStreamWaitEvent(s.ctx->stream, s.ev_comm, 0));
+  }
+  return 0;
+}
+
+extern "C" int nsk_slabs_info(nsk_slabs *g, int *world, int *nlocal, int *transport, int *exchanges) {
+  NSK_GROUP(g, 0);
+  if (world) *world = g->world;
+  if (nlocal) *nlocal = g->nlocal;
+  if (transport) *transport = g->transport;
+  if (exchanges) *exchanges = g->exchanges;
+  return 0;
+}

@@ -38,6 +38,10 @@ C_TO_JULIA = {
     "int *": {"Ptr{Cint}"},
     "nsk_ctx *": {"Ptr{Cvoid}"},
     "nsk_ctx * *": {"Ptr{Ptr{Cvoid}}"},
+    "nsk_slabs *": {"Ptr{Cvoid}"},
+    "nsk_slabs * *": {"Ptr{Ptr{Cvoid}}"},
+    "const int *": {"Ptr{Cint}"},
+    "const void *": {"Ptr{Cvoid}"},
     "void *": {"Ptr{Cvoid}"},
     "const char *": {"Cstring"},
     "const nsk_ns_params *": {"Ref{Params}"},

@@ -1,0 +1,197 @@
+"""The slab decomposition behind the C ABI (nsk_slabs_*, include/nsk.h): several slabs driven by one
+host thread, halo rows moved by device copies or by RCCL.  Only one GPU is available to the tests, so
+all slabs of a group live on cuda:0: the copy transport runs 2-4 slabs there against the
+single-domain oracle (windows, halo bookkeeping, stream/event ordering, scatter/gather of the
+reference's global arrays, the residual and the whole loop NavierStokes.jl:84-95); the RCCL
+transport runs with one slab per communicator -- set-up through a unique id, the all-reduce, and a
+send/receive of row blocks to itself on the communication stream."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from navierstokes_amd import _lib, ns_params
+from navierstokes_amd.ns import c_params
+from util import rng_field, same_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def fields(rng, nx, nyg, scale=1.0):
+    return rng_field(rng, nx, nyg, scale), rng_field(rng, nx - 2, nyg - 2, scale), rng_field(rng, nx, nyg, 10.0 * scale)
+
+
+def oracle_passes(oracle, p, Pr, dP, dv, count):
+    for _ in range(count):
+        oracle.update_dPrdtau(Pr, dP, dv, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy)
+        oracle.update_Pr(Pr, dP, p.dtau)
+        oracle.set_bc_Pr(Pr, 0.0, bool(p.full_rows))
+
+
+def make_group(p, world, ny_loc, halo, transport=2, devices=None):
+    return _lib.Slabs(world, 0, devices or [0] * world, c_params(p), ny_loc, halo, transport=transport)
+
+
+def load(g, Pr, dP, dv):
+    g.upload("Pr", Pr)
+    g.upload("dPrdtau", dP)
+    g.upload("divV", dv)
+
+
+def gathered(g, nx, nyg):
+    Pr, dP = np.full((nx, nyg), np.nan, order="F"), np.full((nx - 2, nyg - 2), np.nan, order="F")
+    g.download("Pr", Pr)
+    g.download("dPrdtau", dP)
+    return Pr, dP
+
+
+@pytest.mark.parametrize("world,ny_loc,halo,count", [(2, 40, 8, 8), (2, 40, 8, 27), (3, 30, 5, 23), (4, 16, 16, 40)])
+def test_copy_transport_matches_single_domain(gpu, oracle, world, ny_loc, halo, count):
+    nx, nyg = 70, world * ny_loc
+    p = ns_params("NavierStokes", nx=nx, ny=nyg)
+    Pr0, dP0, dv = fields(np.random.default_rng(world * 100 + count), nx, nyg)
+    g = make_group(p, world, ny_loc, halo)
+    try:
+        assert g.info() == {"world": world, "nlocal": world, "transport": 2, "exchanges": 0}
+        for i in range(world):
+            w = g.window(i)
+            lo, hi = (halo if i > 0 else 0), (halo if i < world - 1 else 0)
+            assert (w["rank"], w["iy0"], w["ny_win"], w["own_lo"], w["own_hi"]) == \
+                   (i, i * ny_loc - lo, ny_loc + lo + hi, lo, lo + ny_loc)
+            assert w["ld"] % 2 == 0 and w["ld"] > nx and all(g.fields(i).values())
+        load(g, Pr0, dP0, dv)
+        back = gathered(g, nx, nyg)                       # scatter + gather is the identity
+        assert same_bits(back[0], Pr0) and same_bits(back[1], dP0)
+        g.poisson_iters(count)
+        g.sync()
+        assert g.info()["exchanges"] == -(-count // halo)
+        Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
+        oracle_passes(oracle, p, Pr, dP, dv, count)
+        got = gathered(g, nx, nyg)
+        assert same_bits(got[0], Pr), np.argwhere(got[0] != Pr)[:4]
+        assert same_bits(got[1], dP), np.argwhere(got[1] != dP)[:4]
+        Rp = np.zeros((nx - 2, nyg - 2), order="F")
+        oracle.compute_res(Rp, Pr, dv, p.rho, p.dt, p.dx, p.dy)
+        assert g.residual() == oracle.maxabs(Rp)
+    finally:
+        g.close()
+
+
+def test_halo_rows_are_refreshed_by_the_exchange(gpu):
+    """Stale halo rows (as after a kernel that does not update them) are repaired by nsk_slabs_exchange."""
+    world, ny_loc, halo, nx = 3, 20, 6, 33
+    p = ns_params("NavierStokes", nx=nx, ny=world * ny_loc)
+    Pr0, dP0, dv = fields(np.random.default_rng(3), nx, world * ny_loc)
+    g = make_group(p, world, ny_loc, halo)
+    try:
+        load(g, Pr0, dP0, dv)
+        wins = [g.window(i) for i in range(world)]
+        for i, w in enumerate(wins):                      # poison the halo rows of Pr directly in device memory
+            n = w["ny_win"] * w["ld"]
+            host = np.empty(n)
+            _lib.load().nsk_download(gpu.handle, host.ctypes.data_as(C.c_void_p), C.c_void_p(g.fields(i)["Pr"]), n)
+            rows = host.reshape(w["ny_win"], w["ld"])
+            rows[: w["own_lo"]] = 777.0
+            rows[w["own_hi"]:] = -777.0
+            _lib.load().nsk_upload(gpu.handle, C.c_void_p(g.fields(i)["Pr"]), host.ctypes.data_as(C.c_void_p), n)
+        g.exchange(1)
+        g.sync()
+        for i, w in enumerate(wins):
+            n = w["ny_win"] * w["ld"]
+            host = np.empty(n)
+            _lib.load().nsk_download(gpu.handle, host.ctypes.data_as(C.c_void_p), C.c_void_p(g.fields(i)["Pr"]), n)
+            rows = host.reshape(w["ny_win"], w["ld"])[:, :nx]
+            assert same_bits(rows.T, Pr0[:, w["iy0"]:w["iy0"] + w["ny_win"]]), i
+    finally:
+        g.close()
+
+
+def test_whole_loop_with_checks_on_slabs(gpu, oracle):
+    """nsk_slabs_poisson = NavierStokes.jl:84-95 on three slabs: iteration count, (iter, err) history, fields."""
+    world, ny_loc, halo = 3, 35, 7
+    p = ns_params("NavierStokes", nx=63, ny=world * ny_loc, ly=3.0)
+    nx, nyg = p.nx, p.ny
+    rng = np.random.default_rng(5)
+    Pr0, dP0 = np.zeros((nx, nyg), order="F"), np.zeros((nx - 2, nyg - 2), order="F")
+    dv = rng_field(rng, nx, nyg, 0.05)
+    Pr, dP, Rp = Pr0.copy(order="F"), dP0.copy(order="F"), np.zeros((nx - 2, nyg - 2), order="F")
+    it, ih, eh = oracle.poisson(Pr, dP, Rp, dv, p)
+    assert 0 < it < p.niter, "test wants an early exit"
+    g = make_group(p, world, ny_loc, halo)
+    try:
+        load(g, Pr0, dP0, dv)
+        assert g.poisson() == (it, ih, eh)
+        got = gathered(g, nx, nyg)
+        assert same_bits(got[0], Pr) and same_bits(got[1], dP)
+    finally:
+        g.close()
+
+
+def test_slabs_of_the_benchmark_width(gpu, oracle):
+    """2559 cells wide (23 column strips, the vectorised kernel), three slabs of 400 rows, 30 passes, 3 exchanges."""
+    world, ny_loc, halo, count = 3, 400, 12, 30
+    p1 = ns_params("NavierStokes_Re6", n=16)
+    p = p1.with_(ny=world * ny_loc)
+    nx, nyg = p.nx, p.ny
+    Pr0, dP0, dv = fields(np.random.default_rng(9), nx, nyg, 1e-2)
+    g = make_group(p, world, ny_loc, halo)
+    try:
+        load(g, Pr0, dP0, dv)
+        g.poisson_iters(count)
+        Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
+        oracle_passes(oracle, p, Pr, dP, dv, count)
+        got = gathered(g, nx, nyg)
+        assert same_bits(got[0], Pr) and same_bits(got[1], dP)
+        assert g.info()["exchanges"] == 3
+    finally:
+        g.close()
+
+
+def test_rccl_transport_on_one_slab(gpu, oracle):
+    """RCCL path as far as one GPU can take it: library loaded at run time, unique id, communicator of
+    one rank, ncclAllReduce(max) inside the residual, and ncclSend/ncclRecv of row blocks to itself on
+    the communication stream."""
+    uid = _lib.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    nx, ny = 70, 64
+    p = ns_params("NavierStokes", nx=nx, ny=ny, niter=60, nchk=20)
+    Pr0, dP0, dv = fields(np.random.default_rng(12), nx, ny)
+    g = _lib.Slabs(1, 0, [0], c_params(p), ny, 0, transport=1, unique_id=uid)
+    try:
+        assert g.info()["transport"] == 1
+        load(g, Pr0, dP0, dv)
+        Pr, dP, Rp = Pr0.copy(order="F"), dP0.copy(order="F"), np.zeros((nx - 2, ny - 2), order="F")
+        it, ih, eh = oracle.poisson(Pr, dP, Rp, dv, p)
+        assert g.poisson() == (it, ih, eh)                 # every check went through the all-reduce
+        got = gathered(g, nx, ny)
+        assert same_bits(got[0], Pr) and same_bits(got[1], dP)
+        g.call("nsk_slabs_rccl_self_exchange", 9)          # first 9 owned rows of Pr -> divV, through RCCL
+        g.sync()
+        out = np.full((nx, ny), np.nan, order="F")
+        g.download("divV", out)
+        assert same_bits(out[:, :9], Pr[:, :9]) and same_bits(out[:, 9:], dv[:, 9:])
+    finally:
+        g.close()
+
+
+def test_slab_group_misuse_is_reported(gpu):
+    p = ns_params("NavierStokes", nx=33, ny=60)
+    cp = c_params(p)
+    with pytest.raises(_lib.NskError, match="slabs of"):
+        _lib.Slabs(3, 0, [0, 0, 0], cp, 25, 4)             # 3 x 25 != 60 rows
+    with pytest.raises(_lib.NskError, match="halo"):
+        _lib.Slabs(3, 0, [0, 0, 0], cp, 20, 0)
+    with pytest.raises(_lib.NskError, match="every slab in this process"):
+        _lib.Slabs(3, 0, [0], cp, 20, 4, transport=2)
+    with pytest.raises(_lib.NskError, match="id of nsk_rccl_unique_id"):
+        _lib.Slabs(3, 1, [0], cp, 20, 4, transport=1)
+    with pytest.raises(_lib.NskError, match="out of range"):
+        _lib.Slabs(3, 0, [0, 0, 4096], cp, 20, 4)
+    g = _lib.Slabs(3, 0, [0, 0, 0], cp, 20, 4)
+    try:
+        with pytest.raises(_lib.NskError, match="local slab index"):
+            g.window(3)
+        with pytest.raises(_lib.NskError, match="does not use RCCL"):
+            g.call("nsk_slabs_rccl_self_exchange", 2)
+    finally:
+        g.close()
