@@ -105,6 +105,9 @@ def main():
                     help="rehearsal: all ranks share cuda:0 (needs --backend gloo; not a measurement)")
     ap.add_argument("--overlap", action="store_true",
                     help="N>1: boundary bands ahead of the window, halo rows sent while the window is computed")
+    ap.add_argument("--abi-slabs", action="store_true",
+                    help="run the slabs through the C ABI (nsk_slabs_*: RCCL called from the library, one slab "
+                         "per process) instead of the torch.distributed host path")
     ap.add_argument("--time-steps", type=int, default=5,
                     help="additionally run this many whole reference time steps from the IC (N=1)")
     a = ap.parse_args()
@@ -152,7 +155,29 @@ def main():
     be = HipBackend(ctx, p, ld)
     sp = SlabPoisson(p, slab, be, Pr, dP, divV, overlap=a.overlap)
 
+    group = None
+    if a.abi_slabs:
+        # same windows, library-owned; the 128-byte RCCL id travels through torch.distributed once
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(_lib.rccl_unique_id()), dtype=torch.uint8).clone()
+        if world > 1:
+            uid = uid.to(dev) if a.backend == "nccl" else uid
+            dist.broadcast(uid, 0)
+        from navierstokes_amd.ns import c_params
+        group = _lib.Slabs(world, rank, [local], c_params(p), ny_loc, a.halo, transport=1,
+                           unique_id=bytes(uid.cpu().numpy().tobytes()))
+        w, f = group.window(0), group.fields(0)
+        assert (w["ny_win"], w["ld"], w["iy0"]) == (slab.ny_win, ld, slab.iy0)
+        n = slab.ny_win * ld * 8
+        for name, t in (("Pr", Pr), ("dPrdtau", dP), ("divV", divV)):
+            ctx.copy(C.c_void_p(f[name]), C.c_void_p(t.data_ptr()), slab.ny_win * ld)
+        ctx.sync()
+
     def step():
+        if group is not None:
+            group.poisson_iters(passes)
+            return group.residual()
         sp.iterate(passes)
         return sp.residual()
 
@@ -179,6 +204,7 @@ def main():
         dt, exposed = float(tt[0].item()), float(tt[1].item())
 
     # dominant kernel, timed on the stream it runs on: launches of K passes back to back
+    be.poisson_iters(Pr, dP, divV, slab, 16)       # (the library picks the passes per launch on its first call)
     kpl = ctx.get_option("poisson_k")
     nl = 64
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -227,7 +253,7 @@ def main():
                              "(1024 SIMDs x launch cycles at 2.4 GHz); null = no counters for this kernel build"},
     }
     if world > 1:
-        out["schedule"] = "overlapped" if sp.overlap else "plain"
+        out["schedule"] = "abi-slabs (RCCL from the library)" if group is not None else "overlapped" if sp.overlap else "plain"
         out["exchanges_timed"] = n_exch
         out["comm_exposed_us_per_exchange"] = exposed
     if rank == 0 and world == 1 and a.time_steps > 0:
