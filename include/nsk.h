@@ -61,7 +61,10 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *   "poisson_div"          -1 = automatic, 0 / 2 / 3 / 4 = ask for IEEE / 2- / 3- / 4-operation
  *                          division; a form the two divisors dx, dy do not qualify for is replaced
  *                          by the next exact one (2 -> 3 -> 4 -> IEEE)
- *   "poisson_div_used"     (read only) the form the last fused Poisson call ran */
+ *   "poisson_div_used"     (read only) the form the last fused Poisson call ran
+ *   "step_fused"           nsk_ns_step: 1 = three fused kernels around the Poisson loop (default; the
+ *                          stress arrays txx, tyy, txy are then not written), 0 = one launch per
+ *                          call site of NavierStokes.jl:79-100 */
 int nsk_set_option(nsk_ctx *ctx, const char *name, int value);
 int nsk_get_option(nsk_ctx *ctx, const char *name, int *value);
 /* Blocks until all work queued on the context's stream is done. */
@@ -221,7 +224,9 @@ typedef struct nsk_ns_state {
 } nsk_ns_state;
 
 /* One pass of the time-loop body NavierStokes.jl:79-100 on a single domain.
- * Synchronous (the Poisson loop reads the residual back). */
+ * Synchronous (the Poisson loop reads the residual back).  On return Vx, Vy, C, Pr, dPrdtau, divV,
+ * Rp and Vx_o, Vy_o, C_o hold what the reference's arrays hold after :100; txx, tyy, txy only
+ * with the option "step_fused" = 0 (the fused kernels keep the stresses in LDS). */
 int nsk_ns_step(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_params *p,
                 int *iters_out, double *err_hist, int *iter_hist, int hist_cap,
                 int *nhist_out);

@@ -7,6 +7,8 @@ int nsk_i_correct_V(nsk_ctx *ctx, double *Vx, double *Vy, const double *Pr, int 
                     double rho, double dx, double dy, int nx, int ny);
 
 int nsk_i_check_params(const nsk_ns_params *p);
+int nsk_i_step_predictor(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_params *p);
+int nsk_i_step_corrector_advect(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_params *p);
 
 #define NSK_TRY(call)            \
   do {                           \
@@ -24,7 +26,17 @@ extern "C" int nsk_ns_step(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_par
   NSK_REQUIRE(p->iy0 == 0 && p->ny == p->nyg, "nsk_ns_step works on a whole domain");
   const int nx = p->nx, ny = p->ny;
   const int ld = p->ld_pr ? p->ld_pr : nx;
-  // NavierStokes.jl:79-82
+  if (ctx->step_fused) {
+    // Three kernels around the Poisson loop (ns_step_fused.hip); the stress arrays are not
+    // materialised (nothing outside update_τ! / predict_V! reads them).
+    NSK_TRY(nsk_i_step_predictor(ctx, s, p));
+    NSK_TRY(nsk_ns_poisson(ctx, s->Pr, s->dPrdtau, s->Rp, s->divV, p, iters_out, err_hist, iter_hist, hist_cap,
+                           nhist_out));
+    NSK_TRY(nsk_i_step_corrector_advect(ctx, s, p));
+    NSK_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
+  // one launch per call site: NavierStokes.jl:79-82
   NSK_TRY(nsk_update_tau(ctx, s->txx, s->tyy, s->txy, s->Vx, s->Vy, p->mu, p->dx, p->dy, nx, ny));
   NSK_TRY(nsk_predict_V(ctx, s->Vx, s->Vy, s->txx, s->tyy, s->txy, p->rho, p->g, p->dt, p->dx, p->dy, nx, ny));
   NSK_TRY(nsk_set_sphere(ctx, s->C, s->Vx, s->Vy, p->a2, p->b2, p->ox, p->oy, p->sinb, p->cosb, p->lx,

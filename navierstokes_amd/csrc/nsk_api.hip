@@ -108,6 +108,10 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
     ctx->poisson_stage = value != 0;
     return 0;
   }
+  if (!strcmp(name, "step_fused")) {
+    ctx->step_fused = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "poisson_edge_percent")) {
     NSK_REQUIRE(value >= 0 && value <= 100, "poisson_edge_percent must be 0..100, got %d", value);
     ctx->poisson_edge_percent = value;
@@ -140,6 +144,10 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   }
   if (!strcmp(name, "poisson_stage")) {
     *value = ctx->poisson_stage;
+    return 0;
+  }
+  if (!strcmp(name, "step_fused")) {
+    *value = ctx->step_fused;
     return 0;
   }
   if (!strcmp(name, "poisson_xcd")) {

@@ -42,6 +42,7 @@ struct nsk_ctx {
   int last_div = -1;     // form the last fused Poisson call used (nsk_get_option "poisson_div_used")
   int poisson_edge_percent = 0;  // rows per task of the edge strips in % of poisson_rows, 0 = default
   int poisson_xcd = 1;   // XCD-aware task numbering of the Poisson kernel (0 = plain)
+  int step_fused = 1;    // nsk_ns_step: 1 = three fused kernels around the Poisson loop, 0 = one launch per call site
   int poisson_rows = 0;  // rows per task chunk, 0 = automatic (NSK_POISSON_ROWS / nsk_set_option)
 };
 

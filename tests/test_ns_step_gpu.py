@@ -14,12 +14,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-@pytest.mark.parametrize("mode", ["fused", "granular"])
+@pytest.mark.parametrize("mode", ["fused", "fused-call-sites", "granular"])
 def test_steps_small_grid(mode):
+    """fused: nsk_ns_step with three fused kernels around the Poisson loop; fused-call-sites: the same
+    entry point issuing one launch per call site of the reference; granular: one C call per call site."""
     p = ns_params("NavierStokes", nx=45, ny=75)
     if mode == "granular":
         p = p.with_(niter=600)    # one launch per kernel and pass: keep it short
-    sim, ref = NavierStokes(p, mode=mode), OracleSim(p)
+    sim, ref = NavierStokes(p, mode=mode.split("-")[0]), OracleSim(p)
+    sim.ctx.set_option("step_fused", 0 if mode == "fused-call-sites" else 1)
     for _ in range(3):
         assert sim.step() == ref.step()
         assert sim.iter_evo == ref.iter_evo and sim.err_evo == ref.err_evo
@@ -27,6 +30,32 @@ def test_steps_small_grid(mode):
     for k in ("Pr", "Vx", "Vy", "C"):
         assert rel_l2(got[k], getattr(ref, k)) <= TOL, k
         assert same_bits(got[k], getattr(ref, k)), k
+    assert same_bits(sim.dPrdtau_host(), ref.dPrdtau)
+
+
+@pytest.mark.parametrize("nx,ny", [(3, 3), (4, 7), (7, 4), (9, 33), (63, 7), (64, 8), (65, 9), (66, 17), (129, 16),
+                                   (130, 67), (200, 3), (3, 200)])
+@pytest.mark.parametrize("full_rows", [False, True])
+def test_fused_step_kernels_on_ragged_grids(nx, ny, full_rows):
+    """The three fused kernels (64 x 8 tiles with halos, boundary rows written by their neighbours'
+    threads) on grids that do and do not fill their tiles, narrower and wider than tall (the launch
+    range of bc_x! depends on it), with a velocity field that is not at rest: two steps against the
+    oracle, every array the reference keeps."""
+    p = ns_params("NavierStokes", nx=nx, ny=ny, niter=20, nchk=10, full_rows=full_rows)
+    sim, ref = NavierStokes(p), OracleSim(p)
+    rng = np.random.default_rng(nx * 1000 + ny)
+    for k, shape in (("Vx", (nx + 1, ny)), ("Vy", (nx, ny + 1)), ("C", (nx, ny)), ("Pr", (nx, ny))):
+        a = np.asfortranarray(rng.standard_normal(shape) * (0.5 if k != "Pr" else 1e-3))
+        getattr(sim, k).set(a)
+        getattr(ref, k)[...] = a
+    for _ in range(2):
+        assert sim.step() == ref.step()
+        assert sim.err_evo == ref.err_evo
+    got = sim.host_fields()
+    for k in ("Pr", "Vx", "Vy", "C"):
+        assert same_bits(got[k], getattr(ref, k)), (k, np.argwhere(got[k] != getattr(ref, k))[:4])
+    for k in ("Vx_o", "Vy_o", "C_o", "divV"):
+        assert same_bits(getattr(sim, k).get(), getattr(ref, k)), k
     assert same_bits(sim.dPrdtau_host(), ref.dPrdtau)
 
 
