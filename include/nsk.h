@@ -259,8 +259,9 @@ int nsk_slabs_window(nsk_slabs *g, int local, int *rank, int *device, int *iy0, 
                      int *own_lo, int *own_hi, int *ld);
 int nsk_slabs_fields(nsk_slabs *g, int local, double **Pr, double **dPrdtau, double **divV);
 /* Scatter / gather of GLOBAL host arrays in the reference's layout: field 0 = Pr (nx x nyg),
- * 1 = dPrdtau ((nx-2) x (nyg-2)), 2 = divV (nx x nyg).  Upload fills each local window including
- * its halo rows; download writes only the rows the local slabs own.  Synchronous. */
+ * 1 = dPrdtau ((nx-2) x (nyg-2)), 2 = divV (nx x nyg) and, after nsk_slabs_init_flow, 3 = Vx
+ * (nx+1 x nyg), 4 = Vy (nx x nyg+1), 5 = C (nx x nyg).  Upload fills each local window including
+ * its halo rows; download writes only the rows (of Vy: faces) the local slabs own.  Synchronous. */
 int nsk_slabs_upload(nsk_slabs *g, int field, const double *host_global);
 int nsk_slabs_download(nsk_slabs *g, int field, double *host_global);
 /* Refresh the halo rows of the fields in field_mask (bit 0 Pr, bit 1 dPrdtau, bit 2 divV). */
@@ -274,6 +275,14 @@ int nsk_slabs_residual(nsk_slabs *g, double *maxabs_out);
  * outputs as nsk_ns_poisson. */
 int nsk_slabs_poisson(nsk_slabs *g, int *iters_out, double *err_hist, int *iter_hist,
                       int hist_cap, int *nhist_out);
+/* The remaining arrays of runme() (NavierStokes.jl:58-72) as windows on every local slab, zero except
+ * the inflow row Vy[:,1] = Vprof (:73); Vprof_host holds nx values.  Needs halo >= 4. */
+int nsk_slabs_init_flow(nsk_slabs *g, const double *Vprof_host);
+/* One pass of the time-loop body NavierStokes.jl:79-100 on the slab-decomposed grid (outputs as
+ * nsk_ns_step).  The back-trace of advect! must stay inside the halo: reach = max|Vy| dt/dy + 2 >
+ * halo - 1 is an error, not a wrong answer.  Synchronous. */
+int nsk_slabs_step(nsk_slabs *g, int *iters_out, double *err_hist, int *iter_hist, int hist_cap,
+                   int *nhist_out);
 int nsk_slabs_sync(nsk_slabs *g);
 /* Transport check that needs no second GPU (RCCL groups only): every local slab sends the first
  * `rows` owned rows of Pr to itself and receives them into the first `rows` owned rows of divV. */

@@ -221,6 +221,18 @@ function poisson!(s::Slabs; cap=1024)
     n = min(nh[], cap)
     iters[], collect(zip(its[1:n], errs[1:n]))
 end
+"Velocity / tracer windows of runme() on every slab (Vy[:,1] = Vprof on the bottom one)."
+init_flow!(s::Slabs, Vprof::Vector{Float64}) =
+    check(ccall((:nsk_slabs_init_flow, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), s.h, Vprof))
+"One time step (NavierStokes.jl:79-100) on the slabs; returns (iterations, [(iter, err)...])."
+function step!(s::Slabs; cap=1024)
+    iters = Ref{Cint}(0); nh = Ref{Cint}(0)
+    errs = Vector{Cdouble}(undef, cap); its = Vector{Cint}(undef, cap)
+    check(ccall((:nsk_slabs_step, lib), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Cint}, Cint, Ptr{Cint}),
+        s.h, iters, errs, its, cap, nh))
+    n = min(nh[], cap)
+    iters[], collect(zip(its[1:n], errs[1:n]))
+end
 sync(s::Slabs) = check(ccall((:nsk_slabs_sync, lib), Cint, (Ptr{Cvoid},), s.h))
 rccl_self_exchange!(s::Slabs, rows) =
     check(ccall((:nsk_slabs_rccl_self_exchange, lib), Cint, (Ptr{Cvoid}, Cint), s.h, rows))

@@ -108,6 +108,8 @@ _SLAB_SIGS = {
     "nsk_slabs_residual": [c_double_p],
     "nsk_slabs_poisson": [c_int_p, c_double_p, c_int_p, _I, c_int_p],
     "nsk_slabs_sync": [],
+    "nsk_slabs_init_flow": [_P],
+    "nsk_slabs_step": [c_int_p, c_double_p, c_int_p, _I, c_int_p],
     "nsk_slabs_rccl_self_exchange": [_I],
     "nsk_slabs_info": [c_int_p] * 4,
 }
@@ -202,7 +204,7 @@ def rccl_unique_id() -> bytes:
 class Slabs:
     """nsk_slabs: the slabs of this process (include/nsk.h).  transport: 0 auto, 1 RCCL, 2 device copies."""
 
-    FIELDS = {"Pr": 0, "dPrdtau": 1, "divV": 2}
+    FIELDS = {"Pr": 0, "dPrdtau": 1, "divV": 2, "Vx": 3, "Vy": 4, "C": 5}
 
     def __init__(self, world, first_rank, devices, cparams: CNSParams, ny_loc, halo, transport=0, unique_id=None):
         self.lib = load()
@@ -250,6 +252,17 @@ class Slabs:
         iters, nh = C.c_int(0), C.c_int(0)
         he, hi = (C.c_double * cap)(), (C.c_int * cap)()
         self.call("nsk_slabs_poisson", C.byref(iters), he, hi, cap, C.byref(nh))
+        n = min(nh.value, cap)
+        return iters.value, list(hi[:n]), list(he[:n])
+
+    def init_flow(self, vprof) -> None:
+        self.call("nsk_slabs_init_flow", vprof.ctypes.data_as(_P))
+
+    def step(self, cap=1024):
+        """nsk_slabs_step: (iterations, iter history, err history) of one time step."""
+        iters, nh = C.c_int(0), C.c_int(0)
+        he, hi = (C.c_double * cap)(), (C.c_int * cap)()
+        self.call("nsk_slabs_step", C.byref(iters), he, hi, cap, C.byref(nh))
         n = min(nh.value, cap)
         return iters.value, list(hi[:n]), list(he[:n])
 

@@ -87,6 +87,10 @@ struct Slab {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_done = nullptr, ev_comm = nullptr;
   double *Pr = nullptr, *dP = nullptr, *divV = nullptr;  // (ny_win x ld), dPrdτ on the Pr layout
+  // whole-time-step state (nsk_slabs_init_flow), dense windows: Vx (nx+1 x ny_win), Vy (nx x ny_win+1),
+  // the rest (nx x ny_win) and txy (nx-1 x ny_win-1)
+  double *Vx = nullptr, *Vy = nullptr, *C = nullptr, *Vx_o = nullptr, *Vy_o = nullptr, *C_o = nullptr;
+  double *txx = nullptr, *tyy = nullptr, *txy = nullptr, *Vprof = nullptr;
   unsigned long long *red = nullptr;                     // one word for the all-reduce
   ncclComm_t comm = nullptr;
   nsk_ns_params prm{};
@@ -100,19 +104,47 @@ struct nsk_slabs {
   std::vector<Slab> slabs;
   unsigned long long *red_host = nullptr;  // pinned
   int exchanges = 0;
+  bool flow = false;  // the velocity / tracer windows exist
 };
 
 namespace {
 
 inline int pitch_of(int nx) { return (nx + 1 + 15) / 16 * 16; }
 
-// Refresh the halo rows of fields `which` (bit 0 Pr, bit 1 dPrdτ, bit 2 ∇V) of every local slab.
-int exchange_fields(nsk_slabs *g, int which) {
-  if (g->world == 1 || which == 0) return 0;
-  const size_t ld = (size_t)g->ld;
-  const int h = g->halo;
-  const size_t count = (size_t)h * ld;
-  auto field = [&](Slab &s, int f) { return f == 0 ? s.Pr : f == 1 ? s.dP : s.divV; };
+// Fields a slab exchanges halo rows of.  Cell fields have ny_win rows; the face field Vy has
+// ny_win + 1: face f is the lower face of cell row f, a slab owns the faces of its own cell rows
+// (the top slab also the last one), so h + 1 faces travel towards the lower neighbour and h upwards.
+enum { F_PR = 0, F_DP, F_DIVV, F_VX, F_VY, F_C, F_VXO, F_VYO, F_CO, F_COUNT };
+struct XField {
+  int id;
+  size_t ld;
+  bool faces;
+};
+inline double *field_ptr(const Slab &s, int id) {
+  switch (id) {
+    case F_PR: return s.Pr;
+    case F_DP: return s.dP;
+    case F_DIVV: return s.divV;
+    case F_VX: return s.Vx;
+    case F_VY: return s.Vy;
+    case F_C: return s.C;
+    case F_VXO: return s.Vx_o;
+    case F_VYO: return s.Vy_o;
+    case F_CO: return s.C_o;
+  }
+  return nullptr;
+}
+inline XField xfield(const nsk_slabs *g, int id) {
+  const size_t nx = (size_t)g->global.nx;
+  if (id <= F_DIVV) return {id, (size_t)g->ld, false};
+  if (id == F_VX || id == F_VXO) return {id, nx + 1, false};
+  if (id == F_VY || id == F_VYO) return {id, nx, true};
+  return {id, nx, false};
+}
+
+// Refresh `h` halo rows per interior side of the listed fields on every local slab.
+int exchange_list(nsk_slabs *g, const XField *xf, int nf, int h) {
+  if (g->world == 1 || nf == 0 || h == 0) return 0;
   for (Slab &s : g->slabs) {  // transfers start when the slab's kernels are done
     NSK_HIP(hipSetDevice(s.device));
     NSK_HIP(hipEventRecord(s.ev_done, s.ctx->stream));
@@ -126,16 +158,16 @@ int exchange_fields(nsk_slabs *g, int which) {
     NSK_NCCL(R->GroupStart());
     for (Slab &s : g->slabs) {
       NSK_HIP(hipSetDevice(s.device));
-      for (int f = 0; f < 3; f++) {
-        if (!(which & (1 << f))) continue;
-        double *a = field(s, f);
+      for (int f = 0; f < nf; f++) {
+        double *a = field_ptr(s, xf[f].id);
+        const size_t ld = xf[f].ld, up = (size_t)(xf[f].faces ? h + 1 : h) * ld, dn = (size_t)h * ld;
         if (s.rank > 0) {  // lower neighbour: my first owned rows go down, its last owned rows come up
-          NSK_NCCL(R->Send(a + (size_t)s.own_lo * ld, count, ncclDouble, s.rank - 1, s.comm, s.comm_stream));
-          NSK_NCCL(R->Recv(a + (size_t)(s.own_lo - h) * ld, count, ncclDouble, s.rank - 1, s.comm, s.comm_stream));
+          NSK_NCCL(R->Send(a + (size_t)s.own_lo * ld, up, ncclDouble, s.rank - 1, s.comm, s.comm_stream));
+          NSK_NCCL(R->Recv(a + (size_t)(s.own_lo - h) * ld, dn, ncclDouble, s.rank - 1, s.comm, s.comm_stream));
         }
         if (s.rank < g->world - 1) {
-          NSK_NCCL(R->Send(a + (size_t)(s.own_hi - h) * ld, count, ncclDouble, s.rank + 1, s.comm, s.comm_stream));
-          NSK_NCCL(R->Recv(a + (size_t)s.own_hi * ld, count, ncclDouble, s.rank + 1, s.comm, s.comm_stream));
+          NSK_NCCL(R->Send(a + (size_t)(s.own_hi - h) * ld, dn, ncclDouble, s.rank + 1, s.comm, s.comm_stream));
+          NSK_NCCL(R->Recv(a + (size_t)s.own_hi * ld, up, ncclDouble, s.rank + 1, s.comm, s.comm_stream));
         }
       }
     }
@@ -150,32 +182,27 @@ int exchange_fields(nsk_slabs *g, int which) {
     // stream, once its own kernels (which still read and write the halo rows) and the
     // neighbour's (which produce the rows) are done.
     const int n = (int)g->slabs.size();
+    auto copy = [&](Slab &to, double *dst, Slab &from, const double *src, size_t count) -> hipError_t {
+      if (from.device == to.device)
+        return hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, to.comm_stream);
+      return hipMemcpyPeerAsync(dst, to.device, src, from.device, count * sizeof(double), to.comm_stream);
+    };
     for (int i = 0; i < n; i++) {
       Slab &s = g->slabs[i];
       NSK_HIP(hipSetDevice(s.device));
       NSK_HIP(hipStreamWaitEvent(s.comm_stream, s.ev_done, 0));
       if (i > 0) NSK_HIP(hipStreamWaitEvent(s.comm_stream, g->slabs[i - 1].ev_done, 0));
       if (i < n - 1) NSK_HIP(hipStreamWaitEvent(s.comm_stream, g->slabs[i + 1].ev_done, 0));
-      for (int f = 0; f < 3; f++) {
-        if (!(which & (1 << f))) continue;
-        double *a = field(s, f);
-        if (i > 0) {
+      for (int f = 0; f < nf; f++) {
+        double *a = field_ptr(s, xf[f].id);
+        const size_t ld = xf[f].ld, up = (size_t)(xf[f].faces ? h + 1 : h) * ld, dn = (size_t)h * ld;
+        if (i > 0) {  // the lower neighbour's last owned rows
           Slab &lo = g->slabs[i - 1];
-          const double *src = field(lo, f) + (size_t)(lo.own_hi - h) * ld;
-          double *dst = a + (size_t)(s.own_lo - h) * ld;
-          if (lo.device == s.device)
-            NSK_HIP(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, s.comm_stream));
-          else
-            NSK_HIP(hipMemcpyPeerAsync(dst, s.device, src, lo.device, count * sizeof(double), s.comm_stream));
+          NSK_HIP(copy(s, a + (size_t)(s.own_lo - h) * ld, lo, field_ptr(lo, xf[f].id) + (size_t)(lo.own_hi - h) * ld, dn));
         }
-        if (i < n - 1) {
+        if (i < n - 1) {  // the upper neighbour's first owned rows (one more face)
           Slab &hi = g->slabs[i + 1];
-          const double *src = field(hi, f) + (size_t)hi.own_lo * ld;
-          double *dst = a + (size_t)s.own_hi * ld;
-          if (hi.device == s.device)
-            NSK_HIP(hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, s.comm_stream));
-          else
-            NSK_HIP(hipMemcpyPeerAsync(dst, s.device, src, hi.device, count * sizeof(double), s.comm_stream));
+          NSK_HIP(copy(s, a + (size_t)s.own_hi * ld, hi, field_ptr(hi, xf[f].id) + (size_t)hi.own_lo * ld, up));
         }
       }
       NSK_HIP(hipEventRecord(s.ev_comm, s.comm_stream));
@@ -193,13 +220,49 @@ int exchange_fields(nsk_slabs *g, int which) {
   return 0;
 }
 
+// Fields `which` (bit 0 Pr, bit 1 dPrdτ, bit 2 ∇V), `halo` rows.
+int exchange_fields(nsk_slabs *g, int which) {
+  XField xf[3];
+  int nf = 0;
+  for (int f = 0; f < 3; f++)
+    if (which & (1 << f)) xf[nf++] = xfield(g, f);
+  return exchange_list(g, xf, nf, g->halo);
+}
+
+// Maximum over all slabs of the world of a non-negative double given as its bit pattern (the integer
+// order is the IEEE order and NaN stays on top).  `m` holds the maximum over the local slabs.
+int allreduce_max(nsk_slabs *g, unsigned long long *m) {
+  if (g->transport != TRANSPORT_RCCL) return 0;  // all slabs are local
+  Rccl *R = rccl();
+  g->red_host[0] = *m;
+  for (Slab &s : g->slabs) {
+    NSK_HIP(hipSetDevice(s.device));
+    NSK_HIP(hipMemcpyAsync(s.red, g->red_host, sizeof *m, hipMemcpyHostToDevice, s.comm_stream));
+  }
+  NSK_NCCL(R->GroupStart());
+  for (Slab &s : g->slabs) {
+    NSK_HIP(hipSetDevice(s.device));
+    NSK_NCCL(R->AllReduce(s.red, s.red, 1, ncclUint64, ncclMax, s.comm, s.comm_stream));
+  }
+  NSK_NCCL(R->GroupEnd());
+  Slab &s0 = g->slabs[0];
+  NSK_HIP(hipSetDevice(s0.device));
+  NSK_HIP(hipMemcpyAsync(g->red_host + 1, s0.red, sizeof *m, hipMemcpyDeviceToHost, s0.comm_stream));
+  for (Slab &s : g->slabs) {
+    NSK_HIP(hipSetDevice(s.device));
+    NSK_HIP(hipStreamSynchronize(s.comm_stream));
+  }
+  *m = g->red_host[1];
+  return 0;
+}
+
 void release(nsk_slabs *g) {
   for (Slab &s : g->slabs) {
     (void)hipSetDevice(s.device);
     if (s.ctx) (void)hipStreamSynchronize(s.ctx->stream);
     if (s.comm_stream) (void)hipStreamSynchronize(s.comm_stream);
     if (s.comm && rccl()) (void)rccl()->CommDestroy(s.comm);
-    for (double *p : {s.Pr, s.dP, s.divV})
+    for (double *p : {s.Pr, s.dP, s.divV, s.Vx, s.Vy, s.C, s.Vx_o, s.Vy_o, s.C_o, s.txx, s.tyy, s.txy, s.Vprof})
       if (p) (void)hipFree(p);
     if (s.red) (void)hipFree(s.red);
     if (s.ev_done) (void)hipEventDestroy(s.ev_done);
@@ -359,12 +422,17 @@ extern "C" int nsk_slabs_fields(nsk_slabs *g, int local, double **Pr, double **d
 // field: 0 Pr (nx x nyg), 1 dPrdτ ((nx-2) x (nyg-2), the reference's array), 2 ∇V (nx x nyg)
 extern "C" int nsk_slabs_upload(nsk_slabs *g, int field, const double *host) {
   NSK_GROUP(g, 0);
-  NSK_REQUIRE(host != nullptr && field >= 0 && field <= 2, "nsk_slabs_upload: bad arguments");
+  NSK_REQUIRE(host != nullptr && field >= 0 && field <= 5, "nsk_slabs_upload: bad arguments");
+  NSK_REQUIRE(field <= 2 || g->flow, "nsk_slabs_upload: field %d needs nsk_slabs_init_flow first", field);
   const int nx = g->global.nx, nyg = g->ny_loc * g->world;
   const size_t w = sizeof(double);
   for (Slab &s : g->slabs) {
     NSK_HIP(hipSetDevice(s.device));
-    if (field == 1) {  // value of pressure cell (ix, iy) goes to the offset of that cell; the rim is unused
+    if (field >= 3) {  // dense windows of Vx (nx+1 x nyg), Vy (nx x nyg+1), C (nx x nyg), halo rows included
+      const size_t n1 = field == 3 ? nx + 1 : nx, rows = field == 4 ? s.ny_win + 1 : s.ny_win;
+      double *dst = field == 3 ? s.Vx : field == 4 ? s.Vy : s.C;
+      NSK_HIP(hipMemcpyAsync(dst, host + (size_t)s.iy0 * n1, rows * n1 * w, hipMemcpyHostToDevice, s.ctx->stream));
+    } else if (field == 1) {  // value of pressure cell (ix, iy) goes to the offset of that cell; the rim is unused
       const int a = s.iy0 > 1 ? s.iy0 : 1, b = (s.iy0 + s.ny_win < nyg - 1) ? s.iy0 + s.ny_win : nyg - 1;  // Pr rows [a, b)
       NSK_HIP(hipMemcpy2DAsync(s.dP + (size_t)(a - s.iy0) * g->ld + 1, g->ld * w, host + (size_t)(a - 1) * (nx - 2),
                                (size_t)(nx - 2) * w, (size_t)(nx - 2) * w, b - a, hipMemcpyHostToDevice, s.ctx->stream));
@@ -384,13 +452,20 @@ extern "C" int nsk_slabs_upload(nsk_slabs *g, int field, const double *host) {
 // Writes the rows the local slabs own into the global host array (other rows are left alone).
 extern "C" int nsk_slabs_download(nsk_slabs *g, int field, double *host) {
   NSK_GROUP(g, 0);
-  NSK_REQUIRE(host != nullptr && field >= 0 && field <= 2, "nsk_slabs_download: bad arguments");
+  NSK_REQUIRE(host != nullptr && field >= 0 && field <= 5, "nsk_slabs_download: bad arguments");
+  NSK_REQUIRE(field <= 2 || g->flow, "nsk_slabs_download: field %d needs nsk_slabs_init_flow first", field);
   const int nx = g->global.nx, nyg = g->ny_loc * g->world;
   const size_t w = sizeof(double);
   for (Slab &s : g->slabs) {
     NSK_HIP(hipSetDevice(s.device));
     const int g0 = s.iy0 + s.own_lo, g1 = s.iy0 + s.own_hi;  // global rows [g0, g1)
-    if (field == 1) {
+    if (field >= 3) {  // owned rows; of Vy the owned faces, the top slab one more
+      const size_t n1 = field == 3 ? nx + 1 : nx;
+      const int rows = g1 - g0 + ((field == 4 && s.rank == g->world - 1) ? 1 : 0);
+      const double *src = field == 3 ? s.Vx : field == 4 ? s.Vy : s.C;
+      NSK_HIP(hipMemcpyAsync(host + (size_t)g0 * n1, src + (size_t)s.own_lo * n1, (size_t)rows * n1 * w,
+                             hipMemcpyDeviceToHost, s.ctx->stream));
+    } else if (field == 1) {
       const int a = g0 > 1 ? g0 : 1, b = g1 < nyg - 1 ? g1 : nyg - 1;
       NSK_HIP(hipMemcpy2DAsync(host + (size_t)(a - 1) * (nx - 2), (size_t)(nx - 2) * w,
                                s.dP + (size_t)(a - s.iy0) * g->ld + 1, g->ld * w, (size_t)(nx - 2) * w, b - a,
@@ -452,28 +527,7 @@ extern "C" int nsk_slabs_residual(nsk_slabs *g, double *maxabs_out) {
     memcpy(&b, &v, sizeof b);
     m = b > m ? b : m;
   }
-  if (g->transport == TRANSPORT_RCCL) {  // (also with one slab: the reduction is then the identity)
-    Rccl *R = rccl();
-    g->red_host[0] = m;
-    for (Slab &s : g->slabs) {
-      NSK_HIP(hipSetDevice(s.device));
-      NSK_HIP(hipMemcpyAsync(s.red, g->red_host, sizeof m, hipMemcpyHostToDevice, s.comm_stream));
-    }
-    NSK_NCCL(R->GroupStart());
-    for (Slab &s : g->slabs) {
-      NSK_HIP(hipSetDevice(s.device));
-      NSK_NCCL(R->AllReduce(s.red, s.red, 1, ncclUint64, ncclMax, s.comm, s.comm_stream));
-    }
-    NSK_NCCL(R->GroupEnd());
-    Slab &s0 = g->slabs[0];
-    NSK_HIP(hipSetDevice(s0.device));
-    NSK_HIP(hipMemcpyAsync(g->red_host + 1, s0.red, sizeof m, hipMemcpyDeviceToHost, s0.comm_stream));
-    for (Slab &s : g->slabs) {
-      NSK_HIP(hipSetDevice(s.device));
-      NSK_HIP(hipStreamSynchronize(s.comm_stream));
-    }
-    m = g->red_host[1];
-  }
+  if (int rc = allreduce_max(g, &m)) return rc;  // (also with one slab: the reduction is then the identity)
   memcpy(maxabs_out, &m, sizeof m);
   return 0;
 }
@@ -535,6 +589,88 @@ extern "C" int nsk_slabs_rccl_self_exchange(nsk_slabs *g, int rows) {
     NSK_HIP(hipStreamWaitEvent(s.ctx->stream, s.ev_comm, 0));
   }
   return 0;
+}
+
+// Velocity and tracer windows of runme() (NavierStokes.jl:58-72) on every local slab, all zero
+// except the inflow row Vy[:,1] = Vprof (:73) on the bottom slab.  Vprof: nx host values.
+extern "C" int nsk_slabs_init_flow(nsk_slabs *g, const double *Vprof_host) {
+  NSK_GROUP(g, 0);
+  NSK_REQUIRE(Vprof_host != nullptr, "nsk_slabs_init_flow: Vprof is null");
+  NSK_REQUIRE(g->world == 1 || g->halo >= 4, "a slab time step needs at least 4 halo rows, got %d", g->halo);
+  const size_t nx = (size_t)g->global.nx, w = sizeof(double);
+  for (Slab &s : g->slabs) {
+    NSK_HIP(hipSetDevice(s.device));
+    const size_t nw = (size_t)s.ny_win;
+    struct { double **p; size_t n; } arr[] = {
+        {&s.Vx, (nx + 1) * nw}, {&s.Vx_o, (nx + 1) * nw}, {&s.Vy, nx * (nw + 1)}, {&s.Vy_o, nx * (nw + 1)},
+        {&s.C, nx * nw},        {&s.C_o, nx * nw},        {&s.txx, nx * nw},      {&s.tyy, nx * nw},
+        {&s.txy, (nx - 1) * (nw - 1)}, {&s.Vprof, nx}};
+    for (auto &a : arr) {
+      if (!*a.p) NSK_HIP(hipMalloc(a.p, a.n * w));
+      NSK_HIP(hipMemsetAsync(*a.p, 0, a.n * w, s.ctx->stream));
+    }
+    NSK_HIP(hipMemcpyAsync(s.Vprof, Vprof_host, nx * w, hipMemcpyHostToDevice, s.ctx->stream));
+    if (s.iy0 == 0) NSK_HIP(hipMemcpyAsync(s.Vy, Vprof_host, nx * w, hipMemcpyHostToDevice, s.ctx->stream));
+    NSK_HIP(hipStreamSynchronize(s.ctx->stream));
+  }
+  g->flow = true;
+  return 0;
+}
+
+// One pass of the time-loop body NavierStokes.jl:79-100 on the slab-decomposed grid.  The kernels
+// act on whole windows with their guards on global rows; a kernel that needs a neighbour row leaves
+// the window's outermost halo row stale, so validity shrinks by one row per dependent kernel and is
+// restored by exchanges: ∇V before the Poisson loop (which needs all `halo` rows), Pr and dPrdτ
+// inside it, and Vx, Vy, C after advect!.  The back-trace of advect! reaches |V| dt / d + 1 rows; a
+// max|Vy| check over all slabs makes a too narrow halo an error instead of a wrong answer.
+extern "C" int nsk_slabs_step(nsk_slabs *g, int *iters_out, double *err_hist, int *iter_hist, int hist_cap,
+                              int *nhist_out) {
+  NSK_GROUP(g, 0);
+  NSK_REQUIRE(g->flow, "nsk_slabs_step: call nsk_slabs_init_flow first");
+  const nsk_ns_params *p = &g->global;
+  const int nx = p->nx, nyg = g->ny_loc * g->world;
+#define NSK_EACH(call)                          for (Slab &s : g->slabs)                        if (int rc_ = (call)) return rc_
+  // :79-82
+  NSK_EACH(nsk_update_tau(s.ctx, s.txx, s.tyy, s.txy, s.Vx, s.Vy, p->mu, p->dx, p->dy, nx, s.ny_win));
+  NSK_EACH(nsk_predict_V(s.ctx, s.Vx, s.Vy, s.txx, s.tyy, s.txy, p->rho, p->g, p->dt, p->dx, p->dy, nx, s.ny_win));
+  NSK_EACH(nsk_set_sphere(s.ctx, s.C, s.Vx, s.Vy, p->a2, p->b2, p->ox, p->oy, p->sinb, p->cosb, p->lx, p->ly, p->dx,
+                          p->dy, nx, s.ny_win, s.iy0));
+  NSK_EACH(nsk_update_divV_ld(s.ctx, s.divV, g->ld, s.Vx, s.Vy, p->dx, p->dy, nx, s.ny_win));
+  if (int rc = exchange_fields(g, 4)) return rc;
+  // :84-95
+  if (int rc = nsk_slabs_poisson(g, iters_out, err_hist, iter_hist, hist_cap, nhist_out)) return rc;
+  // :96-98
+  NSK_EACH(nsk_correct_V_ld(s.ctx, s.Vx, s.Vy, s.Pr, g->ld, p->dt, p->rho, p->dx, p->dy, nx, s.ny_win));
+  NSK_EACH(nsk_set_sphere(s.ctx, s.C, s.Vx, s.Vy, p->a2, p->b2, p->ox, p->oy, p->sinb, p->cosb, p->lx, p->ly, p->dx,
+                          p->dy, nx, s.ny_win, s.iy0));
+  NSK_EACH(nsk_set_bc_Vel(s.ctx, s.Vx, s.Vy, s.Vprof, nx, s.ny_win, p->full_rows, s.iy0, nyg));
+  if (g->world > 1) {
+    // rows the back-trace may reach: |Vy| dt/dy + 1 below / above; one halo row is already stale
+    // (predict_V! / correct_V! do not update a window's outermost row)
+    unsigned long long m = 0;
+    for (Slab &s : g->slabs) {
+      double v = 0.0;
+      if (int rc = nsk_maxabs(s.ctx, s.Vy, (size_t)nx * (s.ny_win + 1), &v)) return rc;
+      unsigned long long b;
+      memcpy(&b, &v, sizeof b);
+      m = b > m ? b : m;
+    }
+    if (int rc = allreduce_max(g, &m)) return rc;
+    double vmax;
+    memcpy(&vmax, &m, sizeof vmax);
+    const double reach = vmax * p->dt / p->dy + 2;
+    NSK_REQUIRE(reach <= g->halo - 1, "advect! reaches %.1f rows but only %d valid halo rows exist: raise the halo width",
+                reach, g->halo - 1);
+  }
+  // :99-100
+  NSK_EACH(nsk_copy(s.ctx, s.Vx_o, s.Vx, (size_t)(nx + 1) * s.ny_win));
+  NSK_EACH(nsk_copy(s.ctx, s.Vy_o, s.Vy, (size_t)nx * (s.ny_win + 1)));
+  NSK_EACH(nsk_copy(s.ctx, s.C_o, s.C, (size_t)nx * s.ny_win));
+  NSK_EACH(nsk_advect(s.ctx, s.Vx, s.Vx_o, s.Vy, s.Vy_o, s.C, s.C_o, p->dt, p->dx, p->dy, nx, s.ny_win, s.iy0, nyg));
+#undef NSK_EACH
+  const XField xf[3] = {xfield(g, F_VX), xfield(g, F_C), xfield(g, F_VY)};
+  if (int rc = exchange_list(g, xf, 3, g->halo)) return rc;
+  return nsk_slabs_sync(g);
 }
 
 extern "C" int nsk_slabs_info(nsk_slabs *g, int *world, int *nlocal, int *transport, int *exchanges) {

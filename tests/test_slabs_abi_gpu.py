@@ -147,6 +147,55 @@ def test_slabs_of_the_benchmark_width(gpu, oracle):
         g.close()
 
 
+@pytest.mark.parametrize("world,halo,nx,ny_loc,transport", [(2, 8, 45, 40, 2), (3, 12, 54, 30, 2), (1, 0, 45, 60, 1)])
+def test_whole_time_steps_on_slabs(gpu, world, halo, nx, ny_loc, transport):
+    """nsk_slabs_step = NavierStokes.jl:79-100 on slabs (windows of every array, exchanges of divV, Pr,
+    dPrdtau, Vx, C and the face field Vy, the reach check of advect!): three steps from the reference's
+    initial condition against the single-domain oracle; with one slab the RCCL group does the same."""
+    from navierstokes_amd.ns import init_vprof
+    from oracle.ns_oracle import OracleSim
+    nyg = world * ny_loc
+    p = ns_params("NavierStokes", nx=nx, ny=nyg, niter=400, nchk=100)
+    g = _lib.Slabs(world, 0, [0] * world, c_params(p), ny_loc, halo, transport=transport,
+                   unique_id=_lib.rccl_unique_id() if transport == 1 else None)
+    ref = OracleSim(p)
+    try:
+        g.init_flow(init_vprof(p))
+        for _ in range(3):
+            it = ref.step()
+            assert g.step() == (it, ref.iter_evo, ref.err_evo)
+        shapes = {"Pr": (nx, nyg), "Vx": (nx + 1, nyg), "Vy": (nx, nyg + 1), "C": (nx, nyg), "dPrdtau": (nx - 2, nyg - 2)}
+        for k, shp in shapes.items():
+            out = np.full(shp, np.nan, order="F")
+            g.download(k, out)
+            assert same_bits(out, getattr(ref, k)), (k, np.argwhere(out != getattr(ref, k))[:4])
+    finally:
+        g.close()
+
+
+def test_slab_time_step_rejects_a_halo_the_back_trace_would_leave(gpu):
+    from navierstokes_amd.ns import init_vprof
+    p = ns_params("NavierStokes", nx=33, ny=60, niter=20, nchk=10)
+    g = make_group(p, 2, 30, 4)
+    try:
+        with pytest.raises(_lib.NskError, match="init_flow first"):
+            g.step()
+        g.init_flow(init_vprof(p))
+        Vy = np.zeros((33, 61), order="F")
+        Vy[:, 20:40] = 3.0 * p.dy / p.dt              # three rows per step: reach 5 > halo - 1 = 3
+        g.upload("Vy", Vy)
+        with pytest.raises(_lib.NskError, match="raise the halo width"):
+            g.step()
+    finally:
+        g.close()
+    with pytest.raises(_lib.NskError, match="at least 4 halo rows"):
+        g = make_group(p, 2, 30, 3)
+        try:
+            g.init_flow(init_vprof(p))
+        finally:
+            g.close()
+
+
 def test_rccl_transport_on_one_slab(gpu, oracle):
     """RCCL path as far as one GPU can take it: library loaded at run time, unique id, communicator of
     one rank, ncclAllReduce(max) inside the residual, and ncclSend/ncclRecv of row blocks to itself on
