@@ -712,18 +712,22 @@ inline TaskPlan plan_tasks(int K, int nx, int ny, int rows, int edge_percent) {
 }
 
 // Estimated time of a launch with this plan, per pass.  One wavefront per task, at most
-// NSK_WAVES resident per SIMD; a task streams rows + 2K row steps of K passes each.  Measured
-// on MI355X: 0.22 us per row and pass with one wavefront on a SIMD, 0.31 us with two; the memory
-// side moves the three inputs (with their halo re-reads) and the two outputs at about 4.8 TB/s;
-// about 3 us per launch on top.
+// NSK_WAVES resident per SIMD; a task takes rows + 2K row steps, and a row step costs a fixed part
+// (row requests, LDS traffic, stores, index arithmetic) plus a part per pass.  Fitted on MI355X
+// (tools/tune_poisson.py, grids of 159 x 255 up to 2559 x 8191): 0.30 + 0.23 K us per row step with
+// two wavefronts on a SIMD, 0.18 + 0.14 K us with one; the memory side moves the three inputs (with
+// their halo re-reads) and the two outputs at about 5.2 TB/s from HBM, about twice that when the
+// five fields fit the 256 MB last-level cache; about 5 us per launch on top.
 inline double plan_cost(const TaskPlan &t, int nx, int ny, int num_simds) {
   const int K = t.K, HK = (K + 1) & ~1, WOUT = 128 - 2 * HK;
   const long slots = (long)num_simds * NSK_WAVES;
   const double rounds = (double)((t.tasks + slots - 1) / slots);
-  const double per_row = t.tasks > num_simds ? 0.31 : 0.22;
-  const double alu = rounds * (t.rows + 2 * K) * K * per_row;
-  const double mem = 8.0 * nx * ny * (3.0 * (1.0 + 2.0 * K / t.rows) * (128.0 / WOUT) + 2.0) / 4.8e6;
-  return ((alu > mem ? alu : mem) + 3.0) / K;
+  const double per_step = t.tasks > num_simds ? 0.30 + 0.23 * K : 0.18 + 0.14 * K;
+  const double alu = rounds * (t.rows + 2 * K) * per_step;
+  const double field_bytes = 8.0 * nx * ny;
+  const double rate = 5.0 * field_bytes < 200e6 ? 10.4e6 : 5.2e6;  // bytes per us
+  const double mem = field_bytes * (3.0 * (1.0 + 2.0 * K / t.rows) * (128.0 / WOUT) + 2.0) / rate;
+  return ((alu > mem ? alu : mem) + 5.0) / K;
 }
 
 // Passes per launch and chunk height.  k_forced / rows_forced > 0 pin the respective choice;

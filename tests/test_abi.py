@@ -95,7 +95,7 @@ def test_launch_planner_host_logic():
     assert big["rows_edge"] < big["rows"] and 2 <= big["rows"] <= 64
     assert 15000 < big["est_ns_per_pass"] < 30000
     small = _lib.poisson_plan(159, 255)
-    assert small["k"] <= 3 and small["rows"] <= 8 and small["strips"] == 2
+    assert small["k"] <= 4 and small["rows"] <= 8 and small["strips"] == 2
     assert _lib.poisson_plan(2559, 4095, k_limit=3)["k"] <= 3
     assert _lib.poisson_plan(2559, 4095, staged=False)["k"] <= 5
     forced = _lib.poisson_plan(2559, 4095, k=8, rows=200, edge_percent=50)

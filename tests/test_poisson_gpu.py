@@ -263,7 +263,7 @@ def test_planner_picks_passes_per_launch_by_grid(gpu, oracle):
     for opt in ("poisson_k", "poisson_rows"):
         gpu.set_option(opt, 0)
     rng = np.random.default_rng(77)
-    for n, want in ((1, (1, 2, 3)), (16, (5, 6))):
+    for n, want in ((1, (1, 2, 3, 4)), (16, (5, 6))):
         p = ns_params("NavierStokes_Re6", n=n)
         Pr0, dP0, dv = rng_field(rng, p.nx, p.ny, 1e-2), rng_field(rng, p.nx - 2, p.ny - 2, 1e-2), rng_field(rng, p.nx, p.ny, 1e-2)
         run_gpu(gpu, p, Pr0, dP0, dv, 40, 0, True)
