@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--halo", type=int, default=60, help="halo rows = passes between exchanges (N>1)")
     ap.add_argument("--passes", type=int, default=0, help="passes per step (default nchk)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work of the baseline leg (bounded sample)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--one-gpu", action="store_true",
                     help="rehearsal: all ranks share cuda:0 (needs --backend gloo; not a measurement)")
@@ -272,7 +273,7 @@ def main():
                              "us_per_pass_whole_step": [s_ / i * 1e6 for s_, i in zip(secs, its)],
                              "from": "reference initial condition"}
     if rank == 0 and world == 1 and not a.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(p1)
+        out["cpu_baseline"] = cpu_baseline(p1, a.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -1,0 +1,56 @@
+"""bench.py's one-line JSON contract: the keys and types a harness reads, on a short run of the real
+command (a few hundred passes instead of a whole check interval, a one-second CPU sample)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    j = run_bench("--steps", "2", "--warmup", "1", "--passes", "240", "--time-steps", "1", "--cpu-seconds", "1")
+    assert j["metric"] == "T_eff" and j["unit"] == "GB/s" and j["higher_is_better"] is True
+    assert (j["n_gpus"], j["steps"], j["warmup"]) == (1, 2, 1)
+    assert j["dtype"] == "f64" and j["data"] == "synthetic" and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert "2559x4095" in j["config"]["workload"] and "model" not in j["config"]
+    assert j["value"] > 5000 and 5 < j["t_iter_us"] < 80          # the 70 % target is 74.9 us per pass
+    assert abs(j["ms_per_step"] - j["t_iter_us"] * 240 / 1e3) < 1e-6 * j["ms_per_step"] + 1e-9
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "valu") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+    assert r["algorithmic_bytes_per_launch"] == 40.0 * 2559 * 4095 * r["passes_per_launch"]
+    if r["traffic"] is not None:        # counters taken from this very kernel build
+        assert 0.2 < r["hbm_frac"] < 1.0 and 0.2 < r["valu_frac"] < 1.0
+        assert r["traffic"] >= 0.15 * r["algorithmic_bytes_per_launch"]
+    else:
+        assert r["hbm_frac"] is None and r["valu_frac"] is None
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "GB/s" and 1 <= c["cores"] <= c["cores_present"] and c["value"] > 0
+    assert "passes" in c["sample"]
+    t = j["time_steps"]
+    assert t["steps"] == 1 and t["poisson_iters"][0] % 10232 == 0 and t["steps_per_s"] > 0
+
+
+def test_traffic_record_matches_the_build():
+    """profiles/poisson_traffic.json is only used when it was measured on the kernel build in the tree."""
+    from navierstokes_amd._lib import poisson_kernel_hash
+    with open(os.path.join(ROOT, "profiles", "poisson_traffic.json")) as f:
+        rec = json.load(f)
+    entries = {k: v for k, v in rec.items() if k.startswith("k_poisson")}
+    assert entries
+    assert any(v.get("kernel_hash") == poisson_kernel_hash() for v in entries.values()), \
+        "re-run tools/profile_round.sh + tools/make_traffic.py: the kernel source changed after the counters were taken"
