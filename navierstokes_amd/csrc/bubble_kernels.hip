@@ -306,6 +306,123 @@ __global__ void __launch_bounds__(1024) k_sor(SorArgs A) {
   }
 }
 
+// ---- several sweeps in flight ------------------------------------------------------------
+// A lexicographic sweep is a chain of nx+ny-1 anti-diagonals, but sweep k+1 may work on diagonal e
+// as soon as sweep k has finished diagonal e+1: its cells need the values of THIS sweep to the left
+// and below (diagonal e-1) and the values of the PREVIOUS sweep of the cell itself, to the right
+// and above (diagonals e, e+1).  So W sweeps run through the diagonals two apart, each in its own
+// group of G threads ("slot"), all on ONE array in LDS updated in place: in a step the slots write
+// diagonals e, e-2, e-4, ... and read e-1..e+1, e-3..e-1, ..., which never meet, and every value is
+// formed from exactly the operands the serial sweep uses -- the results are identical bit for bit.
+// A new sweep starts every other step instead of every nx+ny-1.
+// The stopping test max|old-new| < maxError belongs to whole sweeps, and by the time sweep k is
+// known to have met it the sweeps behind it have already changed the array.  Every sweep therefore
+// also stores its values into a snapshot of its own in global memory (number k mod R, R = W + 1;
+// stores only, nothing waits for them), and the snapshot of the final sweep is what is copied out;
+// the sweeps behind it were speculation and are dropped.
+// Slot w runs sweeps w+1, w+1+W, ...: sweep (b W + w + 1) works on diagonal e at step
+// 2w + b T + e, T = max(nx+ny-1, 2W).  All counters are kept incrementally (no integer division).
+template <int MODE>
+__global__ void __launch_bounds__(1024) k_sor_pipe(SorArgs A, double *snap, int W, int G) {
+  extern __shared__ double lds[];
+  __shared__ unsigned long long slot_max[32];
+  const int nx = A.nx, ny = A.ny, ld = nx + 2;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int ncell = ld * (ny + 2), R = W + 1;
+  double *a = lds, *c1 = lds + ncell, *c2 = c1 + ncell, *rt = c2 + ncell;
+  for (int k = tid; k < ncell; k += nth) {
+    a[k] = A.a[k];
+    c1[k] = A.c1[k];
+    c2[k] = A.c2[k];
+    if (MODE == 0) rt[k] = A.c3[k];
+  }
+  if (tid < 32) slot_max[tid] = 0;
+  __syncthreads();
+  const double beta = A.beta, dx = A.dx, dy = A.dy;
+  const int ND = nx + ny - 1, T = ND > 2 * W ? ND : 2 * W;
+  const int w = tid / G, lane = tid - w * G;  // this thread's slot and place on the diagonal
+  const int red_lanes = G < 64 ? G : 64;      // lanes of one wavefront that belong to one slot
+  int e = -2 * w, k = w + 1;                  // this slot's diagonal (negative: not started) and sweep
+  double *my_snap = snap + (size_t)(k % R) * ncell;
+  int c = -(ND - 1), batch = 0;               // step counter of the completion test, see below
+  unsigned long long mymax = 0, last = 0;
+  int final_sweep = A.maxit;
+  // every sweep up to maxit is complete after this many steps; the loop ends earlier by itself
+  const long long step_limit = ((long long)A.maxit / W + 2) * T + 2 * W;
+  for (long long t = 0; t < step_limit; t++) {
+    if (w < W && e >= 0 && e < ND && k <= A.maxit) {
+      if (e == 0) mymax = 0;
+      if (e == 1 && lane == 0) slot_max[w] = 0;  // last read a full step ago, next used at e = ND-1 >= 2
+      const int d = e + 4;                       // i + j, i, j in 2..n+1
+      const int ilo = max(2, d - (ny + 1)), ihi = min(nx + 1, d - 2);
+      for (int i = ilo + lane; i <= ihi; i += G) {
+        const int j = d - i;
+        const double old = B2(a, ld, i, j);
+        double nw;
+        if (MODE == 0) {
+          nw = (1.0 - beta) * old +
+               beta * B2(c2, ld, i, j) *
+                   ((1.0 / dx) * (B2(a, ld, i + 1, j) / (dx * (RT(i + 1, j) + RT(i, j))) +
+                                  B2(a, ld, i - 1, j) / (dx * (RT(i - 1, j) + RT(i, j)))) +
+                    (1.0 / dy) * (B2(a, ld, i, j + 1) / (dy * (RT(i, j + 1) + RT(i, j))) +
+                                  B2(a, ld, i, j - 1) / (dy * (RT(i, j - 1) + RT(i, j)))) -
+                    B2(c1, ld, i, j));
+        } else {
+          nw = (1.0 - beta) * old +
+               beta * (0.25 * (B2(a, ld, i + 1, j) + B2(a, ld, i - 1, j) + B2(a, ld, i, j + 1) +
+                               B2(a, ld, i, j - 1) + dx * B2(c1, ld, i - 1, j) - dx * B2(c1, ld, i, j) +
+                               dy * B2(c2, ld, i, j - 1) - dy * B2(c2, ld, i, j)));
+        }
+        B2(a, ld, i, j) = nw;
+        B2(my_snap, ld, i, j) = nw;
+        const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(old - nw));
+        mymax = b > mymax ? b : mymax;
+      }
+      if (e == ND - 1) {  // the sweep is complete: its max|old-new| (integer max of the bit patterns keeps NaN)
+        unsigned long long m = mymax;
+        for (int off = red_lanes >> 1; off > 0; off >>= 1) {
+          const unsigned long long o = __shfl_xor(m, off, 64);
+          m = o > m ? o : m;
+        }
+        if ((lane & (red_lanes - 1)) == 0) atomicMax(&slot_max[w], m);
+      }
+    }
+    if (++e == T) {
+      e = 0;
+      k += W;
+      my_snap = snap + (size_t)(k % R) * ncell;
+    }
+    __syncthreads();  // the step's values and, if a sweep ended, its maximum are visible to everybody
+    // Slot q completes a sweep at steps 2q + ND-1 + b T: c counts steps from ND-1 modulo T, so an
+    // even c below 2W names the slot (at most one per step), `batch` its b.
+    if (c >= 0 && !(c & 1) && (c >> 1) < W) {
+      const int kc = batch * W + (c >> 1) + 1;
+      if (kc <= A.maxit) {
+        last = slot_max[c >> 1];
+        const double ch = __longlong_as_double((long long)last);
+        if (ch < A.maxError || kc == A.maxit) {  // (false for NaN: keeps sweeping, as the reference does)
+          final_sweep = kc;
+          break;
+        }
+      }
+    }
+    if (++c == T) {
+      c = 0;
+      batch++;
+    }
+  }
+  // interior cells of the final sweep's snapshot (ghost cells are never written by a sweep)
+  const double *fin = snap + (size_t)(final_sweep % R) * ncell;
+  for (int q = tid; q < nx * ny; q += nth) {
+    const int j = q / nx, i = q - j * nx;
+    B2(A.a, ld, i + 2, j + 2) = B2(fin, ld, i + 2, j + 2);
+  }
+  if (tid == 0) {
+    if (A.sweeps_out) *A.sweeps_out = final_sweep;
+    if (A.change_out) *A.change_out = __longlong_as_double((long long)last);
+  }
+}
+
 // ---- front kernels ----------------------------------------------------------------------
 
 // code3_fun.jl:372-378: tangents of segments l = 1..Nf+1 (1-based), then tx[Nf+2] = tx[2]
@@ -458,6 +575,43 @@ int launch_sor(nsk_ctx *ctx, int mode, double *a, const double *c1, const double
   double *d_change = reinterpret_cast<double *>(ctx->red_dev + 3);
   SorArgs A{a, c1, c2, c3, beta, dx, dy, maxError, nx, ny, maxit, d_sweeps, d_change};
   const size_t bytes = sizeof(double) * (size_t)(nx + 2) * (ny + 2);
+  {
+    // Several sweeps in flight when the unknown and the coefficient arrays fit the 160 KB of LDS and
+    // a diagonal fits a slot: slots of 32 lanes (two per wavefront) for grids up to 32 cells across.
+    const int nmin = nx < ny ? nx : ny;
+    const int G = nmin <= 32 ? 32 : (nmin + 63) / 64 * 64;
+    int W = G <= 512 ? 1024 / G : 0;
+    const int need = (nx + ny - 1 + 1) / 2;  // more slots than this are never busy together
+    if (W > need) W = need;
+    if (W > maxit) W = maxit;
+    const size_t pbytes = bytes * (mode == 0 ? 4 : 3);
+    if (ctx->sor_pipeline && W >= 2 && pbytes <= 156 * 1024) {
+      const size_t snap_elems = (size_t)(W + 1) * (nx + 2) * (ny + 2);
+      if (ctx->sor_snap_elems < snap_elems) {
+        if (ctx->sor_snap) NSK_HIP(hipFree(ctx->sor_snap));
+        ctx->sor_snap = nullptr;
+        ctx->sor_snap_elems = 0;
+        NSK_HIP(hipMalloc(&ctx->sor_snap, snap_elems * sizeof(double)));
+        ctx->sor_snap_elems = snap_elems;
+      }
+      const int nth = (W * G + 63) / 64 * 64;  // threads past W*G own a slot >= W that never starts
+      if (mode == 0) {
+        NSK_HIP(hipFuncSetAttribute((const void *)k_sor_pipe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pbytes));
+        k_sor_pipe<0><<<1, nth, pbytes, ctx->stream>>>(A, ctx->sor_snap, W, G);
+      } else {
+        NSK_HIP(hipFuncSetAttribute((const void *)k_sor_pipe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pbytes));
+        k_sor_pipe<1><<<1, nth, pbytes, ctx->stream>>>(A, ctx->sor_snap, W, G);
+      }
+      NSK_LAUNCH_CHECK();
+      if (sweeps || change) {
+        NSK_HIP(hipMemcpyAsync(ctx->red_host + 2, ctx->red_dev + 2, 16, hipMemcpyDeviceToHost, ctx->stream));
+        NSK_HIP(hipStreamSynchronize(ctx->stream));
+        if (sweeps) *sweeps = *reinterpret_cast<int *>(ctx->red_host + 2);
+        if (change) *change = *reinterpret_cast<double *>(ctx->red_host + 3);
+      }
+      return 0;
+    }
+  }
   const bool use_lds = bytes <= 128 * 1024;
   const size_t all_bytes = bytes * (mode == 0 ? 4 : 3);
   const bool coef_lds = all_bytes <= 144 * 1024;

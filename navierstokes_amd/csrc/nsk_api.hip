@@ -70,6 +70,7 @@ extern "C" int nsk_destroy(nsk_ctx *c) {
   if (c->pp_dp) (void)hipFree(c->pp_dp);
   if (c->stage) (void)hipFree(c->stage);
   if (c->iter_pp) (void)hipFree(c->iter_pp);
+  if (c->sor_snap) (void)hipFree(c->sor_snap);
   if (c->hist_dev) (void)hipFree(c->hist_dev);
   if (c->hist_host) (void)hipHostFree(c->hist_host);
   delete c;
@@ -112,6 +113,10 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
     ctx->step_fused = value != 0;
     return 0;
   }
+  if (!strcmp(name, "sor_pipeline")) {
+    ctx->sor_pipeline = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "poisson_edge_percent")) {
     NSK_REQUIRE(value >= 0 && value <= 100, "poisson_edge_percent must be 0..100, got %d", value);
     ctx->poisson_edge_percent = value;
@@ -148,6 +153,10 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   }
   if (!strcmp(name, "step_fused")) {
     *value = ctx->step_fused;
+    return 0;
+  }
+  if (!strcmp(name, "sor_pipeline")) {
+    *value = ctx->sor_pipeline;
     return 0;
   }
   if (!strcmp(name, "poisson_xcd")) {

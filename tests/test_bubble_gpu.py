@@ -209,6 +209,43 @@ def test_scalable_pressure_solvers(gpu, bo, nx, ny):
         assert same_bits(dppt.get(), ppt) and same_bits(ddP.get(), dP)
 
 
+@pytest.mark.parametrize("nx,ny", [(2, 2), (3, 7), (31, 33), (32, 32), (33, 20), (64, 64), (66, 60), (70, 45)])
+def test_sor_sweeps_in_flight(gpu, bo, nx, ny):
+    """The lexicographic SOR with several sweeps in flight (grids that fit LDS) and with one sweep at
+    a time give the oracle's values, sweep count and last change: every stopping point from the
+    first sweep to one past a full round of slots, tolerance met early, late and never, NaN."""
+    rng = np.random.default_rng(nx * 977 + ny)
+    dx, dy = 1.0 / nx, 1.3 / ny
+    rt, t2 = rf(rng, nx + 2, ny + 2, 1.0), rf(rng, nx + 2, ny + 2, 0.01)
+    t1, fx, fy = rf(rng, nx + 2, ny + 2), rf(rng, nx + 2, ny + 2), rf(rng, nx + 2, ny + 2)
+    t2 *= dx * dx
+    p0 = rf(rng, nx + 2, ny + 2)
+    pnan = p0.copy(order="F")
+    pnan[1, 1] = np.nan
+    drt, dt1, dt2, dfx, dfy = Dev(rt), Dev(t1), Dev(t2), Dev(fx), Dev(fy)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    cases = [(m, 0.0, p0) for m in (1, 2, 3, 4, 15, 16, 17, 31, 32, 33, 34, 65, 97)]
+    cases += [(400, 1e-2, p0), (400, 1e-5, p0), (40, 1e-300, p0), (37, 1e-3, pnan)]
+    try:
+        for pipe in (1, 0):
+            gpu.set_option("sor_pipeline", pipe)
+            for maxit, tol, start in cases:
+                p, dp_ = start.copy(order="F"), Dev(start)
+                sw, ch, chr_ = C.c_int(0), C.c_double(0.0), C.c_double(0.0)
+                gpu.bub_solve_pressure(dp_.ptr, dt1.ptr, dt2.ptr, drt.ptr, 1.2, dx, dy, nx, ny, maxit, tol, C.byref(sw), C.byref(ch))
+                it = bo.lib.bub_solve_pressure(vp(p), vp(t1), vp(t2), vp(rt), C.c_double(1.2), C.c_double(dx), C.c_double(dy), nx, ny, maxit,
+                                               C.c_double(tol), C.byref(chr_))
+                assert sw.value == it, (pipe, maxit, tol, sw.value, it)
+                assert same_bits(np.array([ch.value]), np.array([chr_.value])), (pipe, maxit, tol)
+                assert same_bits(dp_.get(), p), (pipe, maxit, tol)
+                r, dr = start.copy(order="F"), Dev(start)
+                gpu.bub_construct_den(dr.ptr, dfx.ptr, dfy.ptr, 1.2, maxit, tol, dx, dy, nx, ny, C.byref(sw))
+                it = bo.construct_den(r, fx, fy, 1.2, maxit, tol, dx, dy, nx, ny)
+                assert sw.value == it and same_bits(dr.get(), r), (pipe, maxit, tol, sw.value, it)
+    finally:
+        gpu.set_option("sor_pipeline", 1)
+
+
 def test_solver_nan_runs_to_maxit(gpu, bo):
     """A NaN change never satisfies `< maxError`: both solvers run all maxit iterations."""
     nx = ny = 6
