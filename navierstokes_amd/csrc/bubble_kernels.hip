@@ -444,39 +444,66 @@ __global__ void k_front_tangents(dp tx, dp ty, cdp xf, cdp yf, int Nf) {
 
 // Spreading as a gather (code3_fun.jl:380-401 for KIND 0, :197-222 for KIND 1): grid point
 // (i,j) of fx / fy sums, for l ascending, the weight with which front point l lands on it.
+// The cell a front point lands in, its offsets in that cell and its strength do not depend on the
+// grid point, so the workgroup works them out once per point (SPREAD_CHUNK points at a time, in
+// LDS) and every grid point then only compares cell indices, point after point in the order of
+// the reference's scatter loop.
+constexpr int SPREAD_CHUNK = BX * BY;
 template <int KIND>
-__global__ void k_spread(dp fx, dp fy, cdp xf, cdp yf, cdp tx, cdp ty, double c0, double c1,
-                         double dx, double dy, int nx, int ny, int Nf) {
+__global__ void __launch_bounds__(BX * BY) k_spread(dp fx, dp fy, cdp xf, cdp yf, cdp tx, cdp ty, double c0,
+                                                    double c1, double dx, double dy, int nx, int ny, int Nf) {
+  // cell of a point as one 64-bit key (ip low, jp high): a grid point is hit when the key is one of
+  // its four (i or i-1, j or j-1)
+  __shared__ unsigned long long s_key[2][SPREAD_CHUNK];
+  __shared__ double s_ax[2][SPREAD_CHUNK], s_ay[2][SPREAD_CHUNK], s_nf[2][SPREAD_CHUNK];
   IJ;
-  if (i > nx + 2 || j > ny + 2) return;
+  const int tid = threadIdx.y * BX + threadIdx.x;
+  auto key = [](int ip, int jp) { return (unsigned long long)(unsigned)ip | ((unsigned long long)(unsigned)jp << 32); };
+  const unsigned long long k00 = key(i, j), k10 = key(i - 1, j), k01 = key(i, j - 1), k11 = key(i - 1, j - 1);
   double sx = 0.0, sy = 0.0;
-  for (int l = 2; l <= Nf + 1; l++) {
-    const double xl = xf[l - 1], yl = yf[l - 1];
-    double nfx, nfy;
-    if (KIND == 0) {  // surface tension, c0 = sigma
-      nfx = c0 * (tx[l - 1] - tx[l - 2]);
-      nfy = c0 * (ty[l - 1] - ty[l - 2]);
-    } else {          // density jump, c0 = rho1, c1 = rho2
-      nfx = -0.5 * (yf[l] - yf[l - 2]) * (c1 - c0);
-      nfy = 0.5 * (xf[l] - xf[l - 2]) * (c1 - c0);
-    }
-    {
-      const int ip = (int)floor(xl / dx) + 1, jp = (int)floor((yl + 0.5 * dy) / dy) + 1;
-      if ((i == ip || i == ip + 1) && (j == jp || j == jp + 1)) {
-        const double ax = xl / dx - ip + 1, ay = (yl + 0.5 * dy) / dy - jp + 1;
-        const double wx = i == ip ? 1.0 - ax : ax, wy = j == jp ? 1.0 - ay : ay;
-        sx = sx + wx * wy * nfx / dx / dy;
+  for (int l0 = 2; l0 <= Nf + 1; l0 += SPREAD_CHUNK) {
+    const int l = l0 + tid;
+    if (l <= Nf + 1) {
+      const double xl = xf[l - 1], yl = yf[l - 1];
+      if (KIND == 0) {  // surface tension, c0 = sigma
+        s_nf[0][tid] = c0 * (tx[l - 1] - tx[l - 2]);
+        s_nf[1][tid] = c0 * (ty[l - 1] - ty[l - 2]);
+      } else {          // density jump, c0 = rho1, c1 = rho2
+        s_nf[0][tid] = -0.5 * (yf[l] - yf[l - 2]) * (c1 - c0);
+        s_nf[1][tid] = 0.5 * (xf[l] - xf[l - 2]) * (c1 - c0);
+      }
+      {
+        const int ip = (int)floor(xl / dx) + 1, jp = (int)floor((yl + 0.5 * dy) / dy) + 1;
+        s_key[0][tid] = key(ip, jp);
+        s_ax[0][tid] = xl / dx - ip + 1;
+        s_ay[0][tid] = (yl + 0.5 * dy) / dy - jp + 1;
+      }
+      {
+        const int ip = (int)floor((xl + 0.5 * dx) / dx) + 1, jp = (int)floor(yl / dy) + 1;
+        s_key[1][tid] = key(ip, jp);
+        s_ax[1][tid] = (xl + 0.5 * dx) / dx - ip + 1;
+        s_ay[1][tid] = yl / dy - jp + 1;
       }
     }
-    {
-      const int ip = (int)floor((xl + 0.5 * dx) / dx) + 1, jp = (int)floor(yl / dy) + 1;
-      if ((i == ip || i == ip + 1) && (j == jp || j == jp + 1)) {
-        const double ax = (xl + 0.5 * dx) / dx - ip + 1, ay = yl / dy - jp + 1;
-        const double wx = i == ip ? 1.0 - ax : ax, wy = j == jp ? 1.0 - ay : ay;
-        sy = sy + wx * wy * nfy / dx / dy;
+    __syncthreads();
+    const int n = min(SPREAD_CHUNK, Nf + 2 - l0);
+#pragma unroll 4
+    for (int q = 0; q < n; q++) {
+      const unsigned long long kx = s_key[0][q], ky = s_key[1][q];
+      if (kx == k00 || kx == k10 || kx == k01 || kx == k11) {
+        const double ax = s_ax[0][q], ay = s_ay[0][q];
+        const double wx = (unsigned)kx == (unsigned)i ? 1.0 - ax : ax, wy = (unsigned)(kx >> 32) == (unsigned)j ? 1.0 - ay : ay;
+        sx = sx + wx * wy * s_nf[0][q] / dx / dy;
+      }
+      if (ky == k00 || ky == k10 || ky == k01 || ky == k11) {
+        const double ax = s_ax[1][q], ay = s_ay[1][q];
+        const double wx = (unsigned)ky == (unsigned)i ? 1.0 - ax : ax, wy = (unsigned)(ky >> 32) == (unsigned)j ? 1.0 - ay : ay;
+        sy = sy + wx * wy * s_nf[1][q] / dx / dy;
       }
     }
+    __syncthreads();
   }
+  if (i > nx + 2 || j > ny + 2) return;
   B2(fx, nx + 2, i, j) = sx;
   B2(fy, nx + 2, i, j) = sy;
 }
@@ -526,33 +553,53 @@ __global__ void k_close_front(dp xf, dp yf, int Nf) {
   }
 }
 
-// code3_fun.jl:455-494: regridding reads points it has just written, so it is one thread.
-// xo/yo: scratch copies of the old front.  *Nf_io is updated; -1 signals cap exceeded.
-__global__ void k_regrid_front(dp xf, dp yf, dp xo, dp yo, double dx, double dy, int *Nf_io, int cap) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// code3_fun.jl:455-494: regridding compares every old point with the point written last, so it is
+// one chain: lane 0 walks it with the last point in registers, the other lanes of the wavefront
+// only copy.  xo/yo: scratch copies of the old front.  *Nf_io is updated; -1 signals cap exceeded.
+__global__ void __launch_bounds__(64) k_regrid_front(dp xf, dp yf, dp xo, dp yo, double dx, double dy, int *Nf_io, int cap) {
+  constexpr int LDS_POINTS = 2048;  // fronts up to this size are walked in LDS
+  __shared__ double s_x[LDS_POINTS], s_y[LDS_POINTS];
+  if (blockIdx.x != 0) return;
   const int Nf = *Nf_io;
-  for (int k = 0; k < Nf + 2; k++) {
-    xo[k] = xf[k];
-    yo[k] = yf[k];
+  const bool in_lds = Nf + 2 <= LDS_POINTS;
+  for (int k = threadIdx.x; k < Nf + 2; k += 64) {
+    const double x = xf[k], y = yf[k];
+    xo[k] = x;
+    yo[k] = y;
+    if (in_lds) {
+      s_x[k] = x;
+      s_y[k] = y;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (in_lds) {
+    xo = s_x;
+    yo = s_y;
   }
   int j = 1;
   bool ok = true;
+  double lx = xo[0], ly = yo[0];  // xf[j-1], yf[j-1]: the point written last
+  double nxt_x = xo[1], nxt_y = yo[1];
   for (int l = 2; l <= Nf + 1 && ok; l++) {
-    const double ds = sqrt(SQ((xo[l - 1] - xf[j - 1]) / dx) + SQ((yo[l - 1] - yf[j - 1]) / dy));
+    const double ox = nxt_x, oy = nxt_y;  // xo[l-1], yo[l-1]
+    nxt_x = xo[l];                        // (l <= Nf+1: in range) read ahead of the chain
+    nxt_y = yo[l];
+    const double ds = sqrt(SQ((ox - lx) / dx) + SQ((oy - ly) / dy));
     if (ds > 0.5) {
       j += 1;
       if (j + 2 > cap) { ok = false; break; }
-      xf[j - 1] = 0.5 * (xo[l - 1] + xf[j - 2]);
-      yf[j - 1] = 0.5 * (yo[l - 1] + yf[j - 2]);
+      xf[j - 1] = 0.5 * (ox + lx);
+      yf[j - 1] = 0.5 * (oy + ly);
       j += 1;
-      xf[j - 1] = xo[l - 1];
-      yf[j - 1] = yo[l - 1];
+      xf[j - 1] = lx = ox;
+      yf[j - 1] = ly = oy;
     } else if (ds < 0.25) {
     } else {
       j += 1;
       if (j + 1 > cap) { ok = false; break; }
-      xf[j - 1] = xo[l - 1];
-      yf[j - 1] = yo[l - 1];
+      xf[j - 1] = lx = ox;
+      yf[j - 1] = ly = oy;
     }
   }
   if (!ok || j + 1 > cap) {
@@ -560,8 +607,9 @@ __global__ void k_regrid_front(dp xf, dp yf, dp xo, dp yo, double dx, double dy,
     return;
   }
   const int Nn = j - 1;
-  xf[0] = xf[Nn];
-  yf[0] = yf[Nn];
+  xf[0] = lx;  // xf[Nn]
+  yf[0] = ly;
+  // xf[1] is the first point written (j = 2), or untouched when nothing was written
   xf[Nn + 1] = xf[1];
   yf[Nn + 1] = yf[1];
   *Nf_io = Nn;

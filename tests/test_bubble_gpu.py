@@ -114,7 +114,7 @@ def test_set_density(gpu, bo):
     assert same_bits(dr.get(), r) and same_bits(dm.get(), m) and (r == 2.0).sum() > 10
 
 
-@pytest.mark.parametrize("nx,ny,Nf", [(32, 32, 100), (48, 20, 37), (16, 64, 400)])
+@pytest.mark.parametrize("nx,ny,Nf", [(32, 32, 100), (48, 20, 37), (16, 64, 400), (64, 64, 2600)])
 def test_front_kernels(gpu, bo, nx, ny, Nf):
     q = Code3Params(nx=nx, ny=ny, Nf=Nf)
     dx, dy = q.dx, q.dy

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time steps per second of the two bubble drivers at the reference sizes (32 x 32 cells), GPU
-against the CPU oracle.  At this size the GPU path is launch- and latency-bound; it exists for
-parity, the scalable solvers are timed by tools/time_dns.py."""
+against the CPU oracle.  At this size the GPU path is launch- and latency-bound (one workgroup
+does the SOR solves); the scalable solvers are timed by tools/time_dns.py."""
 import os
 import sys
 import time
