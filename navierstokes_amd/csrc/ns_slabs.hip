@@ -40,19 +40,21 @@ struct Rccl {
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool ok = false;
+  char why[256] = "";  // when not ok
 };
 
-Rccl *rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r.ok ? &r : nullptr;
-  tried = true;
+Rccl load_rccl() {
+  Rccl r;
   // a copy already mapped into the process (a host framework's) is found first by its soname
   for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
     r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (r.handle) break;
   }
-  if (!r.handle) return nullptr;
+  if (!r.handle) {
+    const char *why = dlerror();
+    snprintf(r.why, sizeof r.why, "%s", why ? why : "librccl.so.1 not found");
+    return r;
+  }
 #define NSK_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, sym))
   NSK_SYM(GetUniqueId, "ncclGetUniqueId");
   NSK_SYM(CommInitRank, "ncclCommInitRank");
@@ -66,8 +68,36 @@ Rccl *rccl() {
 #undef NSK_SYM
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv &&
          r.AllReduce && r.GetErrorString;
-  return r.ok ? &r : nullptr;
+  if (!r.ok) snprintf(r.why, sizeof r.why, "the library lacks an entry point this code needs");
+  return r;
 }
+
+// Loaded once (the initialisation of a function-local static is thread-safe); null when unusable.
+const Rccl &rccl_state() {
+  static const Rccl r = load_rccl();
+  return r;
+}
+const Rccl *rccl() { return rccl_state().ok ? &rccl_state() : nullptr; }
+
+// An RCCL group left open by an early return would swallow every later call of the process:
+// the guard closes it on every path.
+struct GroupGuard {
+  const Rccl *R;
+  bool open = false;
+  explicit GroupGuard(const Rccl *r) : R(r) {}
+  ncclResult_t start() {
+    const ncclResult_t e = R->GroupStart();
+    open = e == ncclSuccess;
+    return e;
+  }
+  ncclResult_t end() {
+    open = false;
+    return R->GroupEnd();
+  }
+  ~GroupGuard() {
+    if (open) (void)R->GroupEnd();
+  }
+};
 
 #define NSK_NCCL(call)                                                                              \
   do {                                                                                              \
@@ -150,12 +180,13 @@ int exchange_list(nsk_slabs *g, const XField *xf, int nf, int h) {
     NSK_HIP(hipEventRecord(s.ev_done, s.ctx->stream));
   }
   if (g->transport == TRANSPORT_RCCL) {
-    Rccl *R = rccl();
+    const Rccl *R = rccl();
     for (Slab &s : g->slabs) {
       NSK_HIP(hipSetDevice(s.device));
       NSK_HIP(hipStreamWaitEvent(s.comm_stream, s.ev_done, 0));
     }
-    NSK_NCCL(R->GroupStart());
+    GroupGuard group(R);
+    NSK_NCCL(group.start());
     for (Slab &s : g->slabs) {
       NSK_HIP(hipSetDevice(s.device));
       for (int f = 0; f < nf; f++) {
@@ -171,7 +202,7 @@ int exchange_list(nsk_slabs *g, const XField *xf, int nf, int h) {
         }
       }
     }
-    NSK_NCCL(R->GroupEnd());
+    NSK_NCCL(group.end());
     for (Slab &s : g->slabs) {
       NSK_HIP(hipSetDevice(s.device));
       NSK_HIP(hipEventRecord(s.ev_comm, s.comm_stream));
@@ -233,18 +264,19 @@ int exchange_fields(nsk_slabs *g, int which) {
 // order is the IEEE order and NaN stays on top).  `m` holds the maximum over the local slabs.
 int allreduce_max(nsk_slabs *g, unsigned long long *m) {
   if (g->transport != TRANSPORT_RCCL) return 0;  // all slabs are local
-  Rccl *R = rccl();
+  const Rccl *R = rccl();
   g->red_host[0] = *m;
   for (Slab &s : g->slabs) {
     NSK_HIP(hipSetDevice(s.device));
     NSK_HIP(hipMemcpyAsync(s.red, g->red_host, sizeof *m, hipMemcpyHostToDevice, s.comm_stream));
   }
-  NSK_NCCL(R->GroupStart());
+  GroupGuard group(R);
+  NSK_NCCL(group.start());
   for (Slab &s : g->slabs) {
     NSK_HIP(hipSetDevice(s.device));
     NSK_NCCL(R->AllReduce(s.red, s.red, 1, ncclUint64, ncclMax, s.comm, s.comm_stream));
   }
-  NSK_NCCL(R->GroupEnd());
+  NSK_NCCL(group.end());
   Slab &s0 = g->slabs[0];
   NSK_HIP(hipSetDevice(s0.device));
   NSK_HIP(hipMemcpyAsync(g->red_host + 1, s0.red, sizeof *m, hipMemcpyDeviceToHost, s0.comm_stream));
@@ -282,8 +314,8 @@ void release(nsk_slabs *g) {
 
 extern "C" int nsk_rccl_unique_id(void *id128) {
   NSK_REQUIRE(id128 != nullptr, "nsk_rccl_unique_id: null buffer");
-  Rccl *R = rccl();
-  NSK_REQUIRE(R != nullptr, "RCCL could not be loaded (librccl.so.1): %s", dlerror() ? dlerror() : "symbols missing");
+  const Rccl *R = rccl();
+  NSK_REQUIRE(R != nullptr, "RCCL could not be loaded: %s", rccl_state().why);
   static_assert(sizeof(ncclUniqueId) == 128, "the ABI documents a 128-byte id");
   ncclUniqueId id;
   NSK_NCCL(R->GetUniqueId(&id));
@@ -309,7 +341,7 @@ extern "C" int nsk_slabs_create(int world, int first_rank, int nlocal, const int
               "device copies need every slab in this process (%d of %d are)", nlocal, world);
   ncclUniqueId id;
   if (transport == TRANSPORT_RCCL) {
-    NSK_REQUIRE(rccl() != nullptr, "RCCL could not be loaded (librccl.so.1)");
+    NSK_REQUIRE(rccl() != nullptr, "RCCL could not be loaded: %s", rccl_state().why);
     if (unique_id) {
       memcpy(&id, unique_id, sizeof id);
     } else {
@@ -377,7 +409,7 @@ extern "C" int nsk_slabs_create(int world, int first_rank, int nlocal, const int
     }
     (void)hipGetLastError();
   } else {
-    Rccl *R = rccl();
+    const Rccl *R = rccl();
     bool ok = R->GroupStart() == ncclSuccess;
     for (Slab &s : g->slabs) {
       ok = ok && hipSetDevice(s.device) == hipSuccess;
@@ -569,20 +601,21 @@ extern "C" int nsk_slabs_rccl_self_exchange(nsk_slabs *g, int rows) {
   NSK_GROUP(g, 0);
   NSK_REQUIRE(g->transport == TRANSPORT_RCCL, "the group does not use RCCL");
   NSK_REQUIRE(rows >= 1 && rows <= g->ny_loc, "rows %d outside 1..%d", rows, g->ny_loc);
-  Rccl *R = rccl();
+  const Rccl *R = rccl();
   const size_t ld = (size_t)g->ld, count = (size_t)rows * ld;
   for (Slab &s : g->slabs) {
     NSK_HIP(hipSetDevice(s.device));
     NSK_HIP(hipEventRecord(s.ev_done, s.ctx->stream));
     NSK_HIP(hipStreamWaitEvent(s.comm_stream, s.ev_done, 0));
   }
-  NSK_NCCL(R->GroupStart());
+  GroupGuard group(R);
+  NSK_NCCL(group.start());
   for (Slab &s : g->slabs) {
     NSK_HIP(hipSetDevice(s.device));
     NSK_NCCL(R->Send(s.Pr + (size_t)s.own_lo * ld, count, ncclDouble, s.rank, s.comm, s.comm_stream));
     NSK_NCCL(R->Recv(s.divV + (size_t)s.own_lo * ld, count, ncclDouble, s.rank, s.comm, s.comm_stream));
   }
-  NSK_NCCL(R->GroupEnd());
+  NSK_NCCL(group.end());
   for (Slab &s : g->slabs) {
     NSK_HIP(hipSetDevice(s.device));
     NSK_HIP(hipEventRecord(s.ev_comm, s.comm_stream));
@@ -629,7 +662,9 @@ extern "C" int nsk_slabs_step(nsk_slabs *g, int *iters_out, double *err_hist, in
   NSK_REQUIRE(g->flow, "nsk_slabs_step: call nsk_slabs_init_flow first");
   const nsk_ns_params *p = &g->global;
   const int nx = p->nx, nyg = g->ny_loc * g->world;
-#define NSK_EACH(call)                          for (Slab &s : g->slabs)                        if (int rc_ = (call)) return rc_
+#define NSK_EACH(call)      \
+  for (Slab &s : g->slabs) \
+    if (int rc_ = (call)) return rc_
   // :79-82
   NSK_EACH(nsk_update_tau(s.ctx, s.txx, s.tyy, s.txy, s.Vx, s.Vy, p->mu, p->dx, p->dy, nx, s.ny_win));
   NSK_EACH(nsk_predict_V(s.ctx, s.Vx, s.Vy, s.txx, s.tyy, s.txy, p->rho, p->g, p->dt, p->dx, p->dy, nx, s.ny_win));
