@@ -354,9 +354,10 @@ __global__ void __launch_bounds__(1024) k_sor_pipe(SorArgs A, double *snap, int 
       if (e == 0) mymax = 0;
       if (e == 1 && lane == 0) slot_max[w] = 0;  // last read a full step ago, next used at e = ND-1 >= 2
       const int d = e + 4;                       // i + j, i, j in 2..n+1
-      const int ilo = max(2, d - (ny + 1)), ihi = min(nx + 1, d - 2);
-      for (int i = ilo + lane; i <= ihi; i += G) {
+      // lane <-> column: from one step to the next a lane moves up its column by one row
+      for (int i = 2 + lane; i <= nx + 1; i += G) {
         const int j = d - i;
+        if (j < 2 || j > ny + 1) continue;
         const double old = B2(a, ld, i, j);
         double nw;
         if (MODE == 0) {
