@@ -31,3 +31,11 @@ def test_random_sweep_of_whole_time_steps():
     import fuzz_step
     failures = fuzz_step.sweep(150, 21, 260, verbose=False)
     assert not failures, failures[:5]
+
+
+def test_random_sweep_of_slab_groups(gpu, oracle):
+    """tools/fuzz_slabs.py: 2-6 slabs on cuda:0 through nsk_slabs_* with random heights, halo widths
+    and pass counts (Poisson passes with residual; whole time steps) against the single domain."""
+    import fuzz_slabs
+    failures = fuzz_slabs.sweep(oracle, 250, 31, verbose=False)
+    assert not failures, failures[:5]
