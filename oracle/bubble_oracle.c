@@ -532,7 +532,10 @@ typedef struct {
 } c3_params;
 
 /* One pass of the time loop body, code3_fun.jl:356-494.  sweeps[0..3] receive the SOR sweep
- * counts (pressure, density) of the two substeps.  Returns 0, or -1 if the front outgrew cap. */
+ * counts (pressure, density) of the two substeps.  Returns 0, -1 if the front outgrew cap, or -2
+ * as soon as a front point has left the box: the reference prints a message there
+ * (code3_fun.jl:186-188) and its next array access by that point is a BoundsError; this
+ * restatement indexes unchecked, so it stops instead. */
 int bub_code3_step(c3_state *s, const c3_params *q, int *sweeps) {
   const int nx = q->nx, ny = q->ny;
   const size_t nu = (size_t)(nx + 1) * (ny + 2), nv = (size_t)(nx + 2) * (ny + 1),
@@ -558,6 +561,8 @@ int bub_code3_step(c3_state *s, const c3_params *q, int *sweeps) {
     bub_correct_vvel(s->v, s->vt, s->p, s->r, q->dt, q->dy, nx, ny);
     bub_advect_front(s->uf, s->vf, s->xf, s->yf, s->u, s->v, q->dx, q->dy, nx, s->Nf);
     bub_move_front(s->xf, s->yf, s->uf, s->vf, s->Nf, q->dt, q->Lx, q->Ly);
+    for (int l = 1; l <= s->Nf; l++)  /* (NaN positions count as outside here) */
+      if (!(s->xf[l] >= 0.0 && s->xf[l] <= q->Lx && s->yf[l] >= 0.0 && s->yf[l] <= q->Ly)) return -2;
     bub_distribute(s->fx, s->fy, s->xf, s->yf, q->rho1, q->rho2, q->dx, q->dy, nx, ny, s->Nf);
     int b = bub_construct_den(s->r, s->fx, s->fy, q->beta, q->maxit, q->maxError, q->dx, q->dy, nx, ny);
     bub_update_visco(s->r, s->m, q->m1, q->m2, q->rho1, q->rho2, nx, ny);

@@ -107,6 +107,10 @@ class OracleDNS:
         return it
 
 
+class FrontLeftTheBox(RuntimeError):
+    """The run cannot go on: the reference's next access by that point is out of bounds."""
+
+
 class OracleCode3:
     """code3_fun.jl state stepped by the oracle (parameters = navierstokes_amd.bubble.Code3Params)."""
 
@@ -138,6 +142,8 @@ class OracleCode3:
                       veast=q.veast, dt=q.dt, dx=q.dx, dy=q.dy, maxError=q.maxError, beta=q.beta)
         sw = (C.c_int * 4)()
         rc = self.o.lib.bub_code3_step(C.byref(st), C.byref(pr), sw)
+        if rc == -2:
+            raise FrontLeftTheBox("a front point left the box (code3_fun.jl:186-188)")
         assert rc == 0, "front outgrew its capacity"
         self.Nf = st.Nf
         self.sweeps = list(sw)

@@ -39,3 +39,11 @@ def test_random_sweep_of_slab_groups(gpu, oracle):
     import fuzz_slabs
     failures = fuzz_slabs.sweep(oracle, 250, 31, verbose=False)
     assert not failures, failures[:5]
+
+
+def test_random_sweep_of_the_bubble_drivers():
+    """tools/fuzz_bubble.py: DNS.jl / code3_fun.jl steps with random grids (on both sides of what the
+    several-sweeps-in-flight SOR takes), densities, wall velocities, SOR settings, solvers and fronts."""
+    import fuzz_bubble
+    failures = fuzz_bubble.sweep(150, 41, verbose=False)
+    assert not failures, failures[:5]
