@@ -104,8 +104,11 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--one-gpu", action="store_true",
                     help="rehearsal: all ranks share cuda:0 (needs --backend gloo; not a measurement)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="N>1: boundary bands ahead of the window, halo rows sent while the window is computed")
+    ap.add_argument("--overlap", action="store_true", help="N>1: same as --schedule bands")
+    ap.add_argument("--schedule", choices=["plain", "edges", "bands"], default=None,
+                    help="N>1: plain = passes, then the exchange; edges (default) = the rows to be sent come first in "
+                         "the last launch of a block and travel beside the rest of it; bands = boundary bands ahead of "
+                         "the window")
     ap.add_argument("--abi-slabs", action="store_true",
                     help="run the slabs through the C ABI (nsk_slabs_*: RCCL called from the library, one slab "
                          "per process) instead of the torch.distributed host path")
@@ -154,7 +157,7 @@ def main():
     dP = torch.zeros((slab.ny_win, ld), dtype=torch.float64, device=dev)
     exchange_rows((Pr, divV), slab)
     be = HipBackend(ctx, p, ld)
-    sp = SlabPoisson(p, slab, be, Pr, dP, divV, overlap=a.overlap)
+    sp = SlabPoisson(p, slab, be, Pr, dP, divV, schedule="bands" if a.overlap else a.schedule)
 
     group = None
     if a.abi_slabs:
@@ -254,7 +257,7 @@ def main():
                              "(1024 SIMDs x launch cycles at 2.4 GHz); null = no counters for this kernel build"},
     }
     if world > 1:
-        out["schedule"] = "abi-slabs (RCCL from the library)" if group is not None else "overlapped" if sp.overlap else "plain"
+        out["schedule"] = "abi-slabs (RCCL from the library)" if group is not None else sp.schedule
         out["exchanges_timed"] = n_exch
         out["comm_exposed_us_per_exchange"] = exposed
     if rank == 0 and world == 1 and a.time_steps > 0:

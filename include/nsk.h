@@ -188,6 +188,24 @@ int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau,
 int nsk_ns_poisson_iters_static(nsk_ctx *ctx, double *Pr, double *dPrdtau,
                                 const double *divV, const nsk_ns_params *p, int count);
 
+/* nsk_ns_poisson_iters for a window whose edge rows somebody is waiting for -- the halo exchange
+ * of a slab decomposition (no counterpart in the reference, which is single-device).  Same values
+ * bit for bit.  The last launch of the call is cut in three: the rows
+ * [skip_lo, skip_lo + edge_lo) and [ny - skip_hi - edge_hi, ny - skip_hi) (0-based window rows) are
+ * produced first, by short tasks on edge_stream (a hipStream_t of the context's device); the rows
+ * between them on the context's stream; the first skip_lo and the last skip_hi rows -- halo rows the
+ * caller is about to overwrite with received ones -- are not produced and hold undefined values
+ * afterwards.  Work queued on edge_stream after the call (the transfer: keep it on this stream, a
+ * third stream may share a hardware queue with the interior's) starts as soon as the edge rows are final,
+ * while the interior is still being computed; work queued on the context's stream after the call
+ * sees every row.  When no cut is possible (no rows between the edges, an odd number of launches,
+ * dense arrays iterated on staging copies) the plain sequence runs, all rows are produced, and
+ * edge_stream is ordered behind it.  Asynchronous. */
+int nsk_ns_poisson_iters_edges_first(nsk_ctx *ctx, double *Pr, double *dPrdtau,
+                                     const double *divV, const nsk_ns_params *p, int count,
+                                     int skip_lo, int edge_lo, int edge_hi, int skip_hi,
+                                     void *edge_stream);
+
 /* How nsk_ns_poisson_iters would cut a launch on an nx x ny window: host-only, needs no GPU (no
  * counterpart in the reference; for tuning and tests).  num_simds = 4 x compute units;
  * staged = 1 for pitched storage; k_forced / rows_forced = 0 leave the choice to the planner;
@@ -291,6 +309,11 @@ int nsk_slabs_sync(nsk_slabs *g);
  * `rows` owned rows of Pr to itself and receives them into the first `rows` owned rows of divV. */
 int nsk_slabs_rccl_self_exchange(nsk_slabs *g, int rows);
 int nsk_slabs_info(nsk_slabs *g, int *world, int *nlocal, int *transport, int *exchanges);
+/* Switches with no effect on any result: "edges_first" (default 1) -- the last launch of every
+ * block of Poisson passes produces the rows the neighbours wait for first
+ * (nsk_ns_poisson_iters_edges_first), so that the halo exchange runs beside the rest of that
+ * launch; 0 = whole window, then the exchange. */
+int nsk_slabs_set_option(nsk_slabs *g, const char *name, int value);
 
 /* ---- bubble / drop solvers: scripts/DNS.jl (= scripts/code1.m) and scripts/code3_fun.jl ---
  * Grid arrays are (nx+2) x (ny+2) with one ghost layer; u is (nx+1) x (ny+2), v is

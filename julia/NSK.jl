@@ -123,6 +123,13 @@ poisson_iters!(c, Pr, dPrdτ, ∇V, p::Params, count) =
 poisson_iters_static!(c, Pr, dPrdτ, ∇V, p::Params, count) =
     check(ccall((:nsk_ns_poisson_iters_static, lib), Cint, (Ptr{Cvoid}, PD, PD, PD, Ref{Params}, Cint),
         c.h, Pr.p, dPrdτ.p, ∇V.p, p, count))
+"""The same for a slab window whose edge rows a neighbour waits for: in the last launch the rows
+`skip_lo+1:skip_lo+edge_lo` and their mirror at the other end are produced first, on `edge_stream`
+(a hipStream_t), the first `skip_lo` / last `skip_hi` rows not at all."""
+poisson_iters_edges_first!(c, Pr, dPrdτ, ∇V, p::Params, count, skip_lo, edge_lo, edge_hi, skip_hi, edge_stream::Ptr{Cvoid}) =
+    check(ccall((:nsk_ns_poisson_iters_edges_first, lib), Cint,
+        (Ptr{Cvoid}, PD, PD, PD, Ref{Params}, Cint, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
+        c.h, Pr.p, dPrdτ.p, ∇V.p, p, count, skip_lo, edge_lo, edge_hi, skip_hi, edge_stream))
 function residual(c, Rp, Pr, ∇V, p::Params, own_lo, own_hi)     # compute_res! + maximum(abs.(Rp))
     r = Ref{Cdouble}(0.0)
     check(ccall((:nsk_ns_residual, lib), Cint, (Ptr{Cvoid}, PD, PD, PD, Ref{Params}, Cint, Cint, Ptr{Cdouble}),
@@ -236,6 +243,9 @@ end
 sync(s::Slabs) = check(ccall((:nsk_slabs_sync, lib), Cint, (Ptr{Cvoid},), s.h))
 rccl_self_exchange!(s::Slabs, rows) =
     check(ccall((:nsk_slabs_rccl_self_exchange, lib), Cint, (Ptr{Cvoid}, Cint), s.h, rows))
+"Switches without effect on results, e.g. \"edges_first\" (default 1)."
+set_option!(s::Slabs, name::String, v::Integer) =
+    check(ccall((:nsk_slabs_set_option, lib), Cint, (Ptr{Cvoid}, Cstring, Cint), s.h, name, v))
 function info(s::Slabs)
     v = [Ref{Cint}(0) for _ = 1:4]
     check(ccall((:nsk_slabs_info, lib), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}), s.h, v[1], v[2], v[3], v[4]))

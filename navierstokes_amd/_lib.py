@@ -91,6 +91,7 @@ _SIGS = {
     "nsk_bub_regrid_front": [_P, _P, _P, _P, _D, _D, _I, _I, c_int_p],
     "nsk_ns_poisson_iters": [_P, _P, _P, C.POINTER(CNSParams), _I],
     "nsk_ns_poisson_iters_static": [_P, _P, _P, C.POINTER(CNSParams), _I],
+    "nsk_ns_poisson_iters_edges_first": [_P, _P, _P, C.POINTER(CNSParams), _I, _I, _I, _I, _I, _P],
     "nsk_ns_residual": [_P, _P, _P, C.POINTER(CNSParams), _I, _I, c_double_p],
     "nsk_ns_poisson": [_P, _P, _P, _P, C.POINTER(CNSParams), c_int_p, c_double_p, c_int_p, _I, c_int_p],
     "nsk_ns_step": [C.POINTER(CNSState), C.POINTER(CNSParams), c_int_p, c_double_p, c_int_p, _I, c_int_p],
@@ -112,6 +113,7 @@ _SLAB_SIGS = {
     "nsk_slabs_step": [c_int_p, c_double_p, c_int_p, _I, c_int_p],
     "nsk_slabs_rccl_self_exchange": [_I],
     "nsk_slabs_info": [c_int_p] * 4,
+    "nsk_slabs_set_option": [C.c_char_p, _I],
 }
 
 _lib = None
@@ -268,6 +270,9 @@ class Slabs:
 
     def sync(self) -> None:
         self.call("nsk_slabs_sync")
+
+    def set_option(self, name: str, value: int) -> None:
+        self.call("nsk_slabs_set_option", name.encode(), int(value))
 
     def info(self) -> dict:
         v = [C.c_int(0) for _ in range(4)]

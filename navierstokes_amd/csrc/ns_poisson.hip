@@ -38,7 +38,7 @@ int nsk_read_maxabs(nsk_ctx *ctx, double *out);
 using namespace nsk_poisson;
 
 namespace nsk_poisson {
-#define NSK_DECL(K) extern template int launch_k<K>(nsk_ctx *, PoissonArgs &, bool, int, const TaskPlan &);
+#define NSK_DECL(K) extern template int launch_k<K>(nsk_ctx *, hipStream_t, PoissonArgs &, bool, int, const TaskPlan &);
 NSK_DECL(1) NSK_DECL(2) NSK_DECL(3) NSK_DECL(4) NSK_DECL(5) NSK_DECL(6) NSK_DECL(7) NSK_DECL(8)
 #undef NSK_DECL
 }  // namespace nsk_poisson
@@ -77,16 +77,16 @@ int nsk_i_static_scratch_init(int device, double **out) {
 
 namespace {
 
-int launch_poisson(nsk_ctx *ctx, PoissonArgs &A, bool aligned, int div, const TaskPlan &plan) {
+int launch_poisson(nsk_ctx *ctx, hipStream_t stream, PoissonArgs &A, bool aligned, int div, const TaskPlan &plan) {
   switch (plan.K) {
-    case 1: return launch_k<1>(ctx, A, aligned, div, plan);
-    case 2: return launch_k<2>(ctx, A, aligned, div, plan);
-    case 3: return launch_k<3>(ctx, A, aligned, div, plan);
-    case 4: return launch_k<4>(ctx, A, aligned, div, plan);
-    case 5: return launch_k<5>(ctx, A, aligned, div, plan);
-    case 6: return launch_k<6>(ctx, A, aligned, div, plan);
-    case 7: return launch_k<7>(ctx, A, aligned, div, plan);
-    case 8: return launch_k<8>(ctx, A, aligned, div, plan);
+    case 1: return launch_k<1>(ctx, stream, A, aligned, div, plan);
+    case 2: return launch_k<2>(ctx, stream, A, aligned, div, plan);
+    case 3: return launch_k<3>(ctx, stream, A, aligned, div, plan);
+    case 4: return launch_k<4>(ctx, stream, A, aligned, div, plan);
+    case 5: return launch_k<5>(ctx, stream, A, aligned, div, plan);
+    case 6: return launch_k<6>(ctx, stream, A, aligned, div, plan);
+    case 7: return launch_k<7>(ctx, stream, A, aligned, div, plan);
+    case 8: return launch_k<8>(ctx, stream, A, aligned, div, plan);
   }
   nsk_set_error("passes per launch %d outside 1..8", plan.K);
   return 2;
@@ -285,10 +285,27 @@ bool vector_storage(const double *Pr, const double *dPrdtau, const double *divV,
          ((uintptr_t)dPrdtau % 16 == 0) && ((uintptr_t)divV % 16 == 0);
 }
 
+// Rows of a window whose final values somebody is waiting for (nsk_ns_poisson_iters_edges_first).
+struct EdgesFirst {
+  int skip_lo, edge_lo, edge_hi, skip_hi;
+  hipStream_t stream;  // the caller's stream that is to follow the edge rows
+};
+// Height of the tasks that produce the edge rows in the last launch: short, so that they are done
+// long before the interior's (whose height the planner picks for throughput).
+constexpr int EDGE_TASK_ROWS = 6;
+
 // `count` passes in place, with part_pr / part_dp as the ping-pong partners (same layout as the
-// caller's arrays).  Allocates nothing.
+// caller's arrays).  Allocates nothing.  With `ef`, the last launch is cut in three: the edge rows
+// (both edges in one launch of short tasks, on ef->stream), the interior (on the context's stream)
+// and the skipped rows, which are not produced.  The interior is planned for fewer wavefront slots
+// than the chip has, so that the edge tasks find theirs although the interior is dispatched a few
+// microseconds ahead of them (unplanned, the interior's tasks took every slot and the edge rows
+// were ready no earlier than the interior -- measured).  What the caller queues on ef->stream
+// afterwards (the transfer) follows the edge tasks in that stream's order, on a hardware queue the
+// interior is not on; three streams (edge, interior, transfer) were too many: HIP maps streams
+// onto four hardware queues and two of the three shared one -- measured.
 int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double *divV, const nsk_ns_params *p,
-                        int count, double *part_pr, double *part_dp) {
+                        int count, double *part_pr, double *part_dp, const EdgesFirst *ef = nullptr) {
   const int nx = p->nx, ny = p->ny, ld = ld_pr_of(p), ldd = ld_dp_of(p);
   const bool aligned = vector_storage(Pr, dPrdtau, divV, p);
   const size_t pr_elems = (size_t)ld * ny;
@@ -299,6 +316,9 @@ int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double 
   A.divv = divV;
   A.nx = nx;
   A.ny = ny;
+  A.row_begin = 0;
+  A.row_end = ny;
+  A.row2_begin = A.row2_end = 0;
   A.ld = ld;
   A.ldd = ldd;
   A.dp_embedded = p->dp_embedded;
@@ -336,14 +356,45 @@ int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double 
   if ((nl & 1) && count >= nl + 1) nl++;
   double *src_pr = Pr, *src_dp = dPrdtau, *dst_pr = part_pr, *dst_dp = part_dp;
   int left = count;
+  bool edges_cut = false;
   for (int i = 0; i < nl; i++) {
     int k = (left + (nl - i) - 1) / (nl - i);
     A.pr_src = src_pr;
     A.dp_src = src_dp;
     A.pr_dst = dst_pr;
     A.dp_dst = dst_dp;
-    const TaskPlan plan = k == top.K ? top : choose_plan(nx, ny, ctx->num_simds, aligned, k, k, ctx->poisson_rows, ep);
-    if (int rc = launch_poisson(ctx, A, aligned, div, plan)) return rc;
+    // The cut is made only when the last launch writes into the caller's arrays (an even number
+    // of launches): a copy home afterwards would undo it.
+    if (ef && i == nl - 1 && dst_pr == Pr) {
+      const int lo0 = ef->skip_lo, lo1 = lo0 + ef->edge_lo, hi1 = ny - ef->skip_hi, hi0 = hi1 - ef->edge_hi;
+      NSK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+      NSK_HIP(hipStreamWaitEvent(ef->stream, ctx->ev_fork, 0));
+      // both edges in one launch of short tasks
+      A.row_begin = lo0;
+      A.row_end = lo1;
+      A.row2_begin = hi0;
+      A.row2_end = hi1;
+      const TaskPlan pe = plan_two_ranges(k, nx, lo1 - lo0, hi1 - hi0,
+                                          ctx->edge_task_rows > 0 ? ctx->edge_task_rows : EDGE_TASK_ROWS, ep);
+      if (int rc = launch_poisson(ctx, ef->stream, A, aligned, div, pe)) return rc;
+      NSK_HIP(hipEventRecord(ctx->ev_edge, ef->stream));
+      // the interior, planned for the wavefront slots the edge tasks do not hold
+      A.row_begin = lo1;
+      A.row_end = hi0;
+      A.row2_begin = A.row2_end = 0;
+      long simds_left = ctx->num_simds - (pe.tasks + NSK_WAVES - 1) / NSK_WAVES;
+      if (simds_left < ctx->num_simds / 2) simds_left = ctx->num_simds / 2;
+      const TaskPlan pi = choose_plan(nx, hi0 - lo1, (int)simds_left, aligned, k, k, ctx->poisson_rows, ep);
+      if (int rc = launch_poisson(ctx, ctx->stream, A, aligned, div, pi)) return rc;
+      // later work on the context's stream sees the edge rows as well
+      NSK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_edge, 0));
+      A.row_begin = 0;
+      A.row_end = ny;
+      edges_cut = true;
+    } else {
+      const TaskPlan plan = k == top.K ? top : choose_plan(nx, ny, ctx->num_simds, aligned, k, k, ctx->poisson_rows, ep);
+      if (int rc = launch_poisson(ctx, ctx->stream, A, aligned, div, plan)) return rc;
+    }
     left -= k;
     double *t = src_pr; src_pr = dst_pr; dst_pr = t;
     t = src_dp; src_dp = dst_dp; dst_dp = t;
@@ -351,6 +402,10 @@ int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double 
   if (src_pr != Pr) {  // odd number of launches: bring the result home
     NSK_HIP(hipMemcpyAsync(Pr, src_pr, pr_elems * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     NSK_HIP(hipMemcpyAsync(dPrdtau, src_dp, dp_elems * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  if (ef && !edges_cut) {  // everything ran on the context's stream: the edge stream follows it
+    NSK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    NSK_HIP(hipStreamWaitEvent(ef->stream, ctx->ev_fork, 0));
   }
   return 0;
 }
@@ -371,6 +426,46 @@ extern "C" int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, c
   const size_t dp_elems = p->dp_embedded ? pr_elems : (size_t)ld_dp_of(p) * (p->ny - 2);
   if (int rc = ensure_pingpong(ctx, pr_elems > dp_elems ? pr_elems : dp_elems)) return rc;
   return iters_with_partners(ctx, Pr, dPrdtau, divV, p, count, ctx->pp_pr, ctx->pp_dp);
+}
+
+// nsk_ns_poisson_iters for a window whose edge rows somebody is waiting for (a halo exchange):
+// in the last launch the rows [skip_lo, skip_lo+edge_lo) and [ny-skip_hi-edge_hi, ny-skip_hi) are
+// produced first, by short tasks on `edge_stream`, the rows between them on the context's stream,
+// and the skip_lo first / skip_hi last rows (halo rows about to be received) are not produced: they
+// keep undefined contents.  Work queued on edge_stream afterwards starts when the edge rows are
+// final, i.e. while the interior is still being computed; work queued on the context's stream
+// afterwards sees all rows.  Values are those of nsk_ns_poisson_iters.
+extern "C" int nsk_ns_poisson_iters_edges_first(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double *divV,
+                                                const nsk_ns_params *p, int count, int skip_lo, int edge_lo,
+                                                int edge_hi, int skip_hi, void *edge_stream) {
+  NSK_CTX(ctx);
+  NSK_NONNULL(Pr, dPrdtau, divV);
+  if (int rc = check_params(p)) return rc;
+  NSK_REQUIRE(count >= 0, "negative pass count %d", count);
+  NSK_REQUIRE(edge_stream != nullptr, "nsk_ns_poisson_iters_edges_first: edge_stream is null");
+  NSK_REQUIRE(skip_lo >= 0 && edge_lo >= 0 && edge_hi >= 0 && skip_hi >= 0 &&
+                  (long)skip_lo + edge_lo + edge_hi + skip_hi <= p->ny,
+              "edge rows %d+%d / %d+%d do not fit a window of %d rows", skip_lo, edge_lo, edge_hi, skip_hi, p->ny);
+  if (!ctx->ev_fork) {
+    NSK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    NSK_HIP(hipEventCreateWithFlags(&ctx->ev_edge, hipEventDisableTiming));
+  }
+  EdgesFirst ef{skip_lo, edge_lo, edge_hi, skip_hi, static_cast<hipStream_t>(edge_stream)};
+  const bool pitched = vector_storage(Pr, dPrdtau, divV, p);
+  // no interior rows between the edges, nothing to run ahead, or arrays that are iterated on
+  // staging copies: the plain sequence, with the edge stream ordered behind it
+  const bool cut = count > 0 && (edge_lo > 0 || edge_hi > 0) && skip_lo + edge_lo + edge_hi + skip_hi < p->ny &&
+                   (pitched || !(ctx->poisson_stage && count >= STAGE_MIN_PASSES));
+  if (!cut) {
+    if (int rc = nsk_ns_poisson_iters(ctx, Pr, dPrdtau, divV, p, count)) return rc;
+    NSK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    NSK_HIP(hipStreamWaitEvent(ef.stream, ctx->ev_fork, 0));
+    return 0;
+  }
+  const size_t pr_elems = (size_t)ld_pr_of(p) * p->ny;
+  const size_t dp_elems = p->dp_embedded ? pr_elems : (size_t)ld_dp_of(p) * (p->ny - 2);
+  if (int rc = ensure_pingpong(ctx, pr_elems > dp_elems ? pr_elems : dp_elems)) return rc;
+  return iters_with_partners(ctx, Pr, dPrdtau, divV, p, count, ctx->pp_pr, ctx->pp_dp, &ef);
 }
 
 // nsk_ns_poisson_iters for callers that cannot allocate: the ping-pong partners live in the

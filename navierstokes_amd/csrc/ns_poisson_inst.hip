@@ -3,7 +3,7 @@
 #include "ns_poisson_kernel.h"
 
 namespace nsk_poisson {
-template int launch_k<NSK_K>(nsk_ctx *, PoissonArgs &, bool, int, const TaskPlan &);
+template int launch_k<NSK_K>(nsk_ctx *, hipStream_t, PoissonArgs &, bool, int, const TaskPlan &);
 }  // namespace nsk_poisson
 
 #ifdef NSK_POISSON_TRACE

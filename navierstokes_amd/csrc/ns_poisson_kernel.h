@@ -27,6 +27,10 @@ struct PoissonArgs {
   double *dp_dst;
   int nx, ny, ld, ldd;
   int dp_embedded;
+  // Rows this launch produces: chunks are cut from [row_begin, row_end) and, after those, from a
+  // second range [row2_begin, row2_end) (empty unless the launch serves both edges of a window).
+  int row_begin, row_end, row2_begin, row2_end;
+  int nchunks1, nchunks1_edge;            // chunks of the first range (interior strips / edge strips)
   int nstrips, nchunks, rows_per_chunk;   // interior strips: chunks and rows per chunk
   int nchunks_edge, rows_per_chunk_edge;  // the first and the last strip do more work per row
   int n_interior_tasks;
@@ -651,14 +655,26 @@ __global__ void __launch_bounds__(64) NSK_WAVES_ATTR k_poisson(PoissonArgs A) {
     }
     const int nint = A.nstrips - 2;
     sx = 1 + task % nint;
-    r0 = (task / nint) * A.rows_per_chunk;
-    r1 = min(r0 + A.rows_per_chunk, A.ny);
+    int c = task / nint;
+    if (c < A.nchunks1) {
+      r0 = A.row_begin + c * A.rows_per_chunk;
+      r1 = min(r0 + A.rows_per_chunk, A.row_end);
+    } else {
+      r0 = A.row2_begin + (c - A.nchunks1) * A.rows_per_chunk;
+      r1 = min(r0 + A.rows_per_chunk, A.row2_end);
+    }
   } else {
     task -= A.n_interior_tasks;
     const int nedge = A.nstrips >= 2 ? 2 : 1;
     sx = (task % nedge) == 0 ? 0 : A.nstrips - 1;
-    r0 = (task / nedge) * A.rows_per_chunk_edge;
-    r1 = min(r0 + A.rows_per_chunk_edge, A.ny);
+    int c = task / nedge;
+    if (c < A.nchunks1_edge) {
+      r0 = A.row_begin + c * A.rows_per_chunk_edge;
+      r1 = min(r0 + A.rows_per_chunk_edge, A.row_end);
+    } else {
+      r0 = A.row2_begin + (c - A.nchunks1_edge) * A.rows_per_chunk_edge;
+      r1 = min(r0 + A.rows_per_chunk_edge, A.row2_end);
+    }
   }
   constexpr int HK = (K + 1) & ~1;
   constexpr int WOUT = 128 - 2 * HK;
@@ -689,6 +705,7 @@ struct TaskPlan {
   int K, nstrips, rows, rows_edge, nchunks, nchunks_edge;
   long tasks;
   double est_us_per_pass;
+  int nchunks1 = -1, nchunks1_edge = -1;  // chunks that belong to the first of two row ranges (-1: all)
 };
 
 inline TaskPlan plan_tasks(int K, int nx, int ny, int rows, int edge_percent) {
@@ -708,6 +725,20 @@ inline TaskPlan plan_tasks(int K, int nx, int ny, int rows, int edge_percent) {
   const int nint = t.nstrips > 2 ? t.nstrips - 2 : 0, nedge = t.nstrips >= 2 ? 2 : 1;
   t.tasks = (long)nint * t.nchunks + (long)nedge * t.nchunks_edge;
   t.est_us_per_pass = 0.0;
+  return t;
+}
+
+// One launch over two row ranges of n1 and n2 rows (either may be empty), chunks of `rows` rows
+// (a range shorter than a chunk is one short chunk).
+inline TaskPlan plan_two_ranges(int K, int nx, int n1, int n2, int rows, int edge_percent) {
+  TaskPlan t = plan_tasks(K, nx, n1 + n2 > 0 ? n1 + n2 : 1, rows, edge_percent);  // strips, clamped chunk heights
+  auto chunks = [](int n, int r) { return n > 0 ? (n + r - 1) / r : 0; };
+  t.nchunks1 = chunks(n1, t.rows);
+  t.nchunks1_edge = chunks(n1, t.rows_edge);
+  t.nchunks = t.nchunks1 + chunks(n2, t.rows);
+  t.nchunks_edge = t.nchunks1_edge + chunks(n2, t.rows_edge);
+  const int nint = t.nstrips > 2 ? t.nstrips - 2 : 0, nedge = t.nstrips >= 2 ? 2 : 1;
+  t.tasks = (long)nint * t.nchunks + (long)nedge * t.nchunks_edge;
   return t;
 }
 
@@ -765,17 +796,20 @@ inline TaskPlan choose_plan(int nx, int ny, int num_simds, bool staged, int k_fo
   return best;
 }
 
+// `plan` cuts the rows [A.row_begin, A.row_end) (plan_tasks was given their number).
 template <int K>
-int launch_k(nsk_ctx *ctx, PoissonArgs &A, bool aligned, int div, const TaskPlan &plan) {
+int launch_k(nsk_ctx *ctx, hipStream_t stream, PoissonArgs &A, bool aligned, int div, const TaskPlan &plan) {
   A.nstrips = plan.nstrips;
   A.rows_per_chunk = plan.rows;
   A.nchunks = plan.nchunks;
   A.rows_per_chunk_edge = plan.rows_edge;
   A.nchunks_edge = plan.nchunks_edge;
+  A.nchunks1 = plan.nchunks1 >= 0 ? plan.nchunks1 : plan.nchunks;
+  A.nchunks1_edge = plan.nchunks1_edge >= 0 ? plan.nchunks1_edge : plan.nchunks_edge;
   A.n_interior_tasks = (plan.nstrips > 2 ? plan.nstrips - 2 : 0) * plan.nchunks;
   A.xcd_bands = ctx->poisson_xcd;
   const unsigned tasks = (unsigned)plan.tasks;
-#define NSK_LAUNCH(AL, DV) k_poisson<K, AL, DV><<<tasks, 64, 0, ctx->stream>>>(A)
+#define NSK_LAUNCH(AL, DV) k_poisson<K, AL, DV><<<tasks, 64, 0, stream>>>(A)
   if (aligned) {
     if (div == DIV_FMA2) NSK_LAUNCH(true, DIV_FMA2);
     else if (div == DIV_FMA3) NSK_LAUNCH(true, DIV_FMA3);

@@ -115,6 +115,7 @@ struct Slab {
   int lo_halo = 0, hi_halo = 0, iy0 = 0, ny_win = 0, own_lo = 0, own_hi = 0;  // 0-based window rows, own_hi exclusive
   nsk_ctx *ctx = nullptr;
   hipStream_t comm_stream = nullptr;
+  hipStream_t edge_stream = nullptr;  // last launch of a block: the rows the neighbours wait for
   hipEvent_t ev_done = nullptr, ev_comm = nullptr;
   double *Pr = nullptr, *dP = nullptr, *divV = nullptr;  // (ny_win x ld), dPrdτ on the Pr layout
   // whole-time-step state (nsk_slabs_init_flow), dense windows: Vx (nx+1 x ny_win), Vy (nx x ny_win+1),
@@ -135,6 +136,9 @@ struct nsk_slabs {
   unsigned long long *red_host = nullptr;  // pinned
   int exchanges = 0;
   bool flow = false;  // the velocity / tracer windows exist
+  // Poisson blocks end with the rows to be sent produced first (nsk_ns_poisson_iters_edges_first),
+  // so that they travel while the rest of the window is still being computed
+  bool edges_first = true;
 };
 
 namespace {
@@ -172,18 +176,24 @@ inline XField xfield(const nsk_slabs *g, int id) {
   return {id, nx, false};
 }
 
-// Refresh `h` halo rows per interior side of the listed fields on every local slab.
-int exchange_list(nsk_slabs *g, const XField *xf, int nf, int h) {
+// Refresh `h` halo rows per interior side of the listed fields on every local slab.  The rows to
+// be sent are final when the work queued so far on the slab's stream is done -- or, after
+// nsk_ns_poisson_iters_edges_first, on its edge stream (from_edge).
+int exchange_list(nsk_slabs *g, const XField *xf, int nf, int h, bool from_edge = false) {
   if (g->world == 1 || nf == 0 || h == 0) return 0;
-  for (Slab &s : g->slabs) {  // transfers start when the slab's kernels are done
+  // After an edges-first block the transfer is queued on the edge stream itself, behind the edge
+  // tasks: a third stream could share a hardware queue with the interior's (HIP maps streams onto
+  // four hardware queues) and would then wait for the interior.
+  auto xstream = [&](Slab &s) { return from_edge ? s.edge_stream : s.comm_stream; };
+  for (Slab &s : g->slabs) {  // transfers start when the rows to be sent are final
     NSK_HIP(hipSetDevice(s.device));
-    NSK_HIP(hipEventRecord(s.ev_done, s.ctx->stream));
+    NSK_HIP(hipEventRecord(s.ev_done, from_edge ? s.edge_stream : s.ctx->stream));
   }
   if (g->transport == TRANSPORT_RCCL) {
     const Rccl *R = rccl();
     for (Slab &s : g->slabs) {
       NSK_HIP(hipSetDevice(s.device));
-      NSK_HIP(hipStreamWaitEvent(s.comm_stream, s.ev_done, 0));
+      if (!from_edge) NSK_HIP(hipStreamWaitEvent(s.comm_stream, s.ev_done, 0));
     }
     GroupGuard group(R);
     NSK_NCCL(group.start());
@@ -193,19 +203,19 @@ int exchange_list(nsk_slabs *g, const XField *xf, int nf, int h) {
         double *a = field_ptr(s, xf[f].id);
         const size_t ld = xf[f].ld, up = (size_t)(xf[f].faces ? h + 1 : h) * ld, dn = (size_t)h * ld;
         if (s.rank > 0) {  // lower neighbour: my first owned rows go down, its last owned rows come up
-          NSK_NCCL(R->Send(a + (size_t)s.own_lo * ld, up, ncclDouble, s.rank - 1, s.comm, s.comm_stream));
-          NSK_NCCL(R->Recv(a + (size_t)(s.own_lo - h) * ld, dn, ncclDouble, s.rank - 1, s.comm, s.comm_stream));
+          NSK_NCCL(R->Send(a + (size_t)s.own_lo * ld, up, ncclDouble, s.rank - 1, s.comm, xstream(s)));
+          NSK_NCCL(R->Recv(a + (size_t)(s.own_lo - h) * ld, dn, ncclDouble, s.rank - 1, s.comm, xstream(s)));
         }
         if (s.rank < g->world - 1) {
-          NSK_NCCL(R->Send(a + (size_t)(s.own_hi - h) * ld, dn, ncclDouble, s.rank + 1, s.comm, s.comm_stream));
-          NSK_NCCL(R->Recv(a + (size_t)s.own_hi * ld, up, ncclDouble, s.rank + 1, s.comm, s.comm_stream));
+          NSK_NCCL(R->Send(a + (size_t)(s.own_hi - h) * ld, dn, ncclDouble, s.rank + 1, s.comm, xstream(s)));
+          NSK_NCCL(R->Recv(a + (size_t)s.own_hi * ld, up, ncclDouble, s.rank + 1, s.comm, xstream(s)));
         }
       }
     }
     NSK_NCCL(group.end());
     for (Slab &s : g->slabs) {
       NSK_HIP(hipSetDevice(s.device));
-      NSK_HIP(hipEventRecord(s.ev_comm, s.comm_stream));
+      NSK_HIP(hipEventRecord(s.ev_comm, xstream(s)));
       NSK_HIP(hipStreamWaitEvent(s.ctx->stream, s.ev_comm, 0));
     }
   } else {
@@ -215,15 +225,15 @@ int exchange_list(nsk_slabs *g, const XField *xf, int nf, int h) {
     const int n = (int)g->slabs.size();
     auto copy = [&](Slab &to, double *dst, Slab &from, const double *src, size_t count) -> hipError_t {
       if (from.device == to.device)
-        return hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, to.comm_stream);
-      return hipMemcpyPeerAsync(dst, to.device, src, from.device, count * sizeof(double), to.comm_stream);
+        return hipMemcpyAsync(dst, src, count * sizeof(double), hipMemcpyDeviceToDevice, xstream(to));
+      return hipMemcpyPeerAsync(dst, to.device, src, from.device, count * sizeof(double), xstream(to));
     };
     for (int i = 0; i < n; i++) {
       Slab &s = g->slabs[i];
       NSK_HIP(hipSetDevice(s.device));
-      NSK_HIP(hipStreamWaitEvent(s.comm_stream, s.ev_done, 0));
-      if (i > 0) NSK_HIP(hipStreamWaitEvent(s.comm_stream, g->slabs[i - 1].ev_done, 0));
-      if (i < n - 1) NSK_HIP(hipStreamWaitEvent(s.comm_stream, g->slabs[i + 1].ev_done, 0));
+      if (!from_edge) NSK_HIP(hipStreamWaitEvent(s.comm_stream, s.ev_done, 0));
+      if (i > 0) NSK_HIP(hipStreamWaitEvent(xstream(s), g->slabs[i - 1].ev_done, 0));
+      if (i < n - 1) NSK_HIP(hipStreamWaitEvent(xstream(s), g->slabs[i + 1].ev_done, 0));
       for (int f = 0; f < nf; f++) {
         double *a = field_ptr(s, xf[f].id);
         const size_t ld = xf[f].ld, up = (size_t)(xf[f].faces ? h + 1 : h) * ld, dn = (size_t)h * ld;
@@ -236,7 +246,7 @@ int exchange_list(nsk_slabs *g, const XField *xf, int nf, int h) {
           NSK_HIP(copy(s, a + (size_t)s.own_hi * ld, hi, field_ptr(hi, xf[f].id) + (size_t)hi.own_lo * ld, up));
         }
       }
-      NSK_HIP(hipEventRecord(s.ev_comm, s.comm_stream));
+      NSK_HIP(hipEventRecord(s.ev_comm, xstream(s)));
     }
     // a slab's kernels go on when its halo rows have arrived and its neighbours have read its rows
     for (int i = 0; i < n; i++) {
@@ -252,12 +262,12 @@ int exchange_list(nsk_slabs *g, const XField *xf, int nf, int h) {
 }
 
 // Fields `which` (bit 0 Pr, bit 1 dPrdτ, bit 2 ∇V), `halo` rows.
-int exchange_fields(nsk_slabs *g, int which) {
+int exchange_fields(nsk_slabs *g, int which, bool from_edge = false) {
   XField xf[3];
   int nf = 0;
   for (int f = 0; f < 3; f++)
     if (which & (1 << f)) xf[nf++] = xfield(g, f);
-  return exchange_list(g, xf, nf, g->halo);
+  return exchange_list(g, xf, nf, g->halo, from_edge);
 }
 
 // Maximum over all slabs of the world of a non-negative double given as its bit pattern (the integer
@@ -293,6 +303,10 @@ void release(nsk_slabs *g) {
     (void)hipSetDevice(s.device);
     if (s.ctx) (void)hipStreamSynchronize(s.ctx->stream);
     if (s.comm_stream) (void)hipStreamSynchronize(s.comm_stream);
+    if (s.edge_stream) {
+      (void)hipStreamSynchronize(s.edge_stream);
+      (void)hipStreamDestroy(s.edge_stream);
+    }
     if (s.comm && rccl()) (void)rccl()->CommDestroy(s.comm);
     for (double *p : {s.Pr, s.dP, s.divV, s.Vx, s.Vy, s.C, s.Vx_o, s.Vy_o, s.C_o, s.txx, s.tyy, s.txy, s.Vprof})
       if (p) (void)hipFree(p);
@@ -388,6 +402,7 @@ extern "C" int nsk_slabs_create(int world, int first_rank, int nlocal, const int
     NSK_FAIL_IF(nsk_create(s.device, &s.ctx) != 0, "slab %d: %s", s.rank, nsk_last_error());
     const size_t bytes = (size_t)s.ny_win * g->ld * sizeof(double);
     bool ok = hipStreamCreateWithFlags(&s.comm_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&s.edge_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&s.ev_comm, hipEventDisableTiming) == hipSuccess &&
               hipMalloc(&s.red, 64) == hipSuccess;
@@ -526,6 +541,7 @@ extern "C" int nsk_slabs_sync(nsk_slabs *g) {
   for (Slab &s : g->slabs) {
     NSK_HIP(hipSetDevice(s.device));
     NSK_HIP(hipStreamSynchronize(s.comm_stream));
+    NSK_HIP(hipStreamSynchronize(s.edge_stream));
     NSK_HIP(hipStreamSynchronize(s.ctx->stream));
   }
   return 0;
@@ -537,9 +553,17 @@ extern "C" int nsk_slabs_poisson_iters(nsk_slabs *g, int count) {
   int left = count;
   while (left > 0) {
     const int n = g->world == 1 ? left : (left < g->halo ? left : g->halo);
-    for (Slab &s : g->slabs)
-      if (int rc = nsk_ns_poisson_iters(s.ctx, s.Pr, s.dP, s.divV, &s.prm, n)) return rc;
-    if (int rc = exchange_fields(g, 3)) return rc;
+    // rows to be sent first, halo rows (about to be received) not at all in the block's last launch,
+    // when a slab has rows left between its two edges
+    const bool ef = g->edges_first && g->world > 1 && g->ny_loc > 2 * g->halo;
+    for (Slab &s : g->slabs) {
+      const int rc = ef ? nsk_ns_poisson_iters_edges_first(s.ctx, s.Pr, s.dP, s.divV, &s.prm, n, s.lo_halo,
+                                                           s.lo_halo ? g->halo : 0, s.hi_halo ? g->halo : 0,
+                                                           s.hi_halo, s.edge_stream)
+                        : nsk_ns_poisson_iters(s.ctx, s.Pr, s.dP, s.divV, &s.prm, n);
+      if (rc) return rc;
+    }
+    if (int rc = exchange_fields(g, 3, ef)) return rc;
     left -= n;
   }
   return 0;
@@ -706,6 +730,17 @@ extern "C" int nsk_slabs_step(nsk_slabs *g, int *iters_out, double *err_hist, in
   const XField xf[3] = {xfield(g, F_VX), xfield(g, F_C), xfield(g, F_VY)};
   if (int rc = exchange_list(g, xf, 3, g->halo)) return rc;
   return nsk_slabs_sync(g);
+}
+
+extern "C" int nsk_slabs_set_option(nsk_slabs *g, const char *name, int value) {
+  NSK_GROUP(g, 0);
+  NSK_REQUIRE(name != nullptr, "nsk_slabs_set_option: name is null");
+  if (!strcmp(name, "edges_first")) {
+    g->edges_first = value != 0;
+    return 0;
+  }
+  nsk_set_error("nsk_slabs_set_option: unknown option '%s'", name);
+  return 2;
 }
 
 extern "C" int nsk_slabs_info(nsk_slabs *g, int *world, int *nlocal, int *transport, int *exchanges) {

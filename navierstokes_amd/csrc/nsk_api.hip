@@ -71,6 +71,8 @@ extern "C" int nsk_destroy(nsk_ctx *c) {
   if (c->stage) (void)hipFree(c->stage);
   if (c->iter_pp) (void)hipFree(c->iter_pp);
   if (c->sor_snap) (void)hipFree(c->sor_snap);
+  if (c->ev_edge) (void)hipEventDestroy(c->ev_edge);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->hist_dev) (void)hipFree(c->hist_dev);
   if (c->hist_host) (void)hipHostFree(c->hist_host);
   delete c;
@@ -117,6 +119,11 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
     ctx->sor_pipeline = value != 0;
     return 0;
   }
+  if (!strcmp(name, "poisson_edge_task_rows")) {
+    NSK_REQUIRE(value >= 0, "poisson_edge_task_rows must be >= 0, got %d", value);
+    ctx->edge_task_rows = value;
+    return 0;
+  }
   if (!strcmp(name, "poisson_edge_percent")) {
     NSK_REQUIRE(value >= 0 && value <= 100, "poisson_edge_percent must be 0..100, got %d", value);
     ctx->poisson_edge_percent = value;
@@ -157,6 +164,10 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   }
   if (!strcmp(name, "sor_pipeline")) {
     *value = ctx->sor_pipeline;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_edge_task_rows")) {
+    *value = ctx->edge_task_rows;
     return 0;
   }
   if (!strcmp(name, "poisson_xcd")) {

@@ -42,6 +42,9 @@ struct nsk_ctx {
   int last_div = -1;     // form the last fused Poisson call used (nsk_get_option "poisson_div_used")
   int poisson_edge_percent = 0;  // rows per task of the edge strips in % of poisson_rows, 0 = default
   int poisson_xcd = 1;   // XCD-aware task numbering of the Poisson kernel (0 = plain)
+  int edge_task_rows = 0;  // task height of the edge rows in nsk_ns_poisson_iters_edges_first, 0 = default
+  // nsk_ns_poisson_iters_edges_first (created on first use): fork and edge-rows-final events
+  hipEvent_t ev_fork = nullptr, ev_edge = nullptr;
   int sor_pipeline = 1;  // lexicographic SOR: 1 = several sweeps in flight when everything fits LDS, 0 = one at a time
   double *sor_snap = nullptr;  // per-sweep snapshots of the unknown for that kernel
   size_t sor_snap_elems = 0;

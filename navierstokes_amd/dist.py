@@ -14,8 +14,15 @@ same inputs.  The residual check (NavierStokes.jl:89-90) is a local max over own
 followed by one MAX all-reduce of the value's bit pattern (|x| >= 0, so the integer order is
 the IEEE order and NaN stays the largest).
 
-Overlap: the rows a neighbour is waiting for are the `halo` owned rows next to an interior
-edge, final only after the last pass of a block of `halo` passes.  To have them early, each
+Overlap ("edges" schedule, the default on the GPU): the rows a neighbour is waiting for are the
+`halo` owned rows next to an interior edge, final only after the last pass of a block of `halo`
+passes.  The library cuts the last launch of a block in three (nsk_ns_poisson_iters_edges_first):
+short tasks produce those rows on a second stream, the halo rows -- about to be received -- are
+not produced at all, and the rest of the window runs on the main stream; the exchange is ordered
+behind the second stream only, so the rows travel while the last launch is still running.  No
+extra arithmetic, same values.
+
+The older "bands" schedule hides the transfer behind a whole block instead: each
 block first advances a *band* of 3*halo rows around each interior edge (a copy of those rows,
 run as a window of its own on a second stream): after the block's passes its middle
 `halo` rows are exactly the rows to send.  They travel on a communication stream while the
@@ -82,16 +89,20 @@ def make_slab(rank: int, world: int, ny_loc: int, halo: int) -> Slab:
     return Slab(rank, world, ny_loc, halo if world > 1 else 0, ny_loc * world)
 
 
-def exchange_rows(fields, slab: Slab, nrows: Optional[int] = None, faces: bool = False) -> None:
+def exchange_rows(fields, slab: Slab, nrows: Optional[int] = None, faces: bool = False, wait: bool = True):
     """Refresh the halo rows of every field in `fields` (tensors shaped (rows, ld), row = iy)
     from the neighbours' owned rows.  One batched isend/irecv per neighbour and field.
 
     Cell fields have ny_win rows.  Face fields (faces=True: Vy) have ny_win+1 rows; face f is
     the lower face of cell row f, a rank owns the faces of its own cell rows (the top rank
     also the last face), so the window of the lower neighbour ends one face later than its
-    cell halo: h+1 faces travel downwards, h upwards."""
+    cell halo: h+1 faces travel downwards, h upwards.
+
+    wait=False (device-to-device transports only) returns the requests instead of waiting: the
+    transfer is ordered behind the stream that is current now, and whoever calls .wait() on the
+    requests later makes the stream current THEN wait for it."""
     if slab.world == 1:
-        return
+        return []
     h = slab.halo if nrows is None else nrows
     up = h + 1 if faces else h            # rows that travel towards the lower neighbour
     lo, hi = slab.own_lo, slab.own_hi
@@ -118,10 +129,14 @@ def exchange_rows(fields, slab: Slab, nrows: Optional[int] = None, faces: bool =
         if slab.rank < slab.world - 1:          # upper neighbour: send my last rows, get its first
             send(t, hi - h, hi, slab.rank + 1)
             recv(t, hi, hi + up, slab.rank + 1)
-    for r in dist.batch_isend_irecv(ops):
+    reqs = dist.batch_isend_irecv(ops)
+    if not wait and not stage:
+        return reqs
+    for r in reqs:
         r.wait()
     for t, a, b, buf in landing:
         t[a:b].copy_(buf)
+    return []
 
 
 def allreduce_maxabs(value: float, device) -> float:
@@ -170,25 +185,44 @@ class SlabPoisson:
         residual_max(Pr, divV, slab) -> float               -- max|Rp| over the owned rows
     on tensors shaped (ny_win, ld); `window` is a Slab or a Band (iy0, nyg, ny_win).
 
-    overlap: False (default) = passes, then the exchange; True = boundary bands ahead of the window
-    (needs 2*halo owned rows per rank); "auto" = overlapped when the geometry allows.  On one
-    MI355X the overlapped schedule costs more than it can hide (the window's launches fill every
-    wavefront slot of the chip, so band launches push them back; tools/overlap_overhead.py), hence
-    the default."""
+    schedule: "plain" = passes, then the exchange; "edges" = the rows to be sent are produced first in
+    the last launch of a block and travel beside the rest of it (needs a backend with
+    poisson_iters_edges and more than 2*halo owned rows per rank); "bands" = boundary bands ahead
+    of the window (needs 2*halo owned rows per rank; on one MI355X it costs more than it can hide:
+    the window's launches fill every wavefront slot of the chip, so band launches push them back,
+    tools/overlap_overhead.py).  None = "edges" where possible, else "plain".  overlap=True is the
+    old spelling of schedule="bands", overlap="auto" of "bands where the geometry allows"."""
 
-    def __init__(self, p: NSParams, slab: Slab, backend, Pr, dP, divV, overlap=False):
+    def __init__(self, p: NSParams, slab: Slab, backend, Pr, dP, divV, overlap=False, schedule=None):
         self.p, self.slab, self.be = p, slab, backend
         self.Pr, self.dP, self.divV = Pr, dP, divV
         fits = slab.world > 1 and slab.ny_loc >= 2 * slab.halo
-        if overlap is True and slab.world > 1 and not fits:
+        if schedule is None and overlap:
+            schedule = "bands" if (overlap is True or fits) else "plain"
+        can_edges = (slab.world > 1 and slab.ny_loc > 2 * slab.halo and Pr.is_cuda
+                     and hasattr(backend, "poisson_iters_edges"))
+        if schedule is None:
+            schedule = "edges" if can_edges else "plain"
+        if schedule not in ("plain", "edges", "bands"):
+            raise ValueError(f"unknown schedule {schedule!r}")
+        if schedule == "bands" and slab.world > 1 and not fits:
             raise ValueError(f"overlapped exchange needs at least 2*halo = {2 * slab.halo} owned rows per rank, "
                              f"got {slab.ny_loc}")
-        self.overlap = bool(overlap) and fits
+        if schedule == "edges" and slab.world > 1 and not can_edges:
+            raise ValueError("the edges-first schedule needs the HIP backend and more than 2*halo owned rows per rank")
+        if slab.world == 1:
+            schedule = "plain"
+        self.schedule = schedule
+        self.overlap = schedule == "bands"
+        if schedule == "edges":
+            self.edge_stream = torch.cuda.Stream(device=Pr.device)
         self.bands = []
         self.exchanges = 0
         self.timing = False          # True: keep an event pair per exchange (exposed_us())
         self.loopback = False        # True: no peers; halo rows are refilled by device copies of the
                                      # rank's own rows (timing of the compute side only, wrong values)
+        self.loopback_wire = 0       # loopback only: spin this many torch.cuda._sleep cycles where the
+                                     # transfer would run (a stand-in for latency + wire time)
         self._marks = []
         if self.overlap:
             if slab.rank > 0:
@@ -210,6 +244,8 @@ class SlabPoisson:
         mark = self._mark()
         if self.loopback:
             s, h = self.slab, self.slab.halo
+            if self.loopback_wire:
+                torch.cuda._sleep(self.loopback_wire)
             for t in (self.Pr, self.dP):
                 if s.rank > 0:
                     t[:h].copy_(t[s.own_lo:s.own_lo + h])
@@ -217,6 +253,36 @@ class SlabPoisson:
                     t[s.own_hi:].copy_(t[s.own_hi - h:s.own_hi])
         else:
             exchange_rows((self.Pr, self.dP), self.slab)
+        self._mark(mark)
+
+    def _block_edges(self, n: int) -> None:
+        s, h = self.slab, self.slab.halo
+        main = torch.cuda.current_stream(self.Pr.device)
+        # main stream: all launches but the last, then the interior rows of the last one;
+        # edge stream: the rows the neighbours wait for, in short tasks
+        self.be.poisson_iters_edges(self.Pr, self.dP, self.divV, s, n, self.edge_stream)
+        mark = self._mark()
+        if self.loopback:
+            # the stand-in for the transfer follows the edge tasks on their own stream: a third stream
+            # may share a hardware queue with the main stream's and would then wait for the interior
+            with torch.cuda.stream(self.edge_stream):
+                if self.loopback_wire:
+                    torch.cuda._sleep(self.loopback_wire)
+                for t in (self.Pr, self.dP):
+                    if s.rank > 0:
+                        t[:h].copy_(t[s.own_lo:s.own_lo + h])
+                    if s.rank < s.world - 1:
+                        t[s.own_hi:].copy_(t[s.own_hi - h:s.own_hi])
+            main.wait_stream(self.edge_stream)
+        elif dist.get_backend() == "gloo":
+            # host-staged transport (tests): nothing to overlap; the library has already ordered the
+            # main stream behind the edge rows
+            exchange_rows((self.Pr, self.dP), s)
+        else:
+            with torch.cuda.stream(self.edge_stream):      # RCCL: ordered behind the edge rows only
+                reqs = exchange_rows((self.Pr, self.dP), s, wait=False)
+            for r in reqs:
+                r.wait()                                   # the main stream (not the host) waits
         self._mark(mark)
 
     def _block_overlapped(self, n: int) -> None:
@@ -305,8 +371,10 @@ class SlabPoisson:
         left = count
         while left > 0:
             n = min(left, s.halo)
-            if self.overlap:
+            if self.schedule == "bands":
                 self._block_overlapped(n)
+            elif self.schedule == "edges":
+                self._block_edges(n)
             else:
                 self._block_plain(n)
             self.exchanges += 1
@@ -401,6 +469,17 @@ class HipBackend:
         ctx.ns_poisson_iters(C.c_void_p(Pr.data_ptr()), C.c_void_p(dP.data_ptr()),
                              C.c_void_p(divV.data_ptr()), C.byref(cp), int(count))
 
+    def poisson_iters_edges(self, Pr, dP, divV, slab, count, edge_stream):
+        """`count` passes; in the last launch the `halo` owned rows next to each interior edge come
+        first, on `edge_stream`, and the halo rows are left to the exchange that follows."""
+        C = self.C
+        cp = self._cp(slab)
+        h = slab.halo
+        self.ctx.ns_poisson_iters_edges_first(C.c_void_p(Pr.data_ptr()), C.c_void_p(dP.data_ptr()),
+                                              C.c_void_p(divV.data_ptr()), C.byref(cp), int(count),
+                                              slab.lo_halo, h if slab.lo_halo else 0, h if slab.hi_halo else 0,
+                                              slab.hi_halo, C.c_void_p(edge_stream.cuda_stream))
+
     def residual_max(self, Pr, divV, slab):
         C = self.C
         cp = self._cp(slab)
@@ -427,7 +506,7 @@ class SlabNavierStokes:
         poisson_iters, residual_max                          (see SlabPoisson)
     """
 
-    def __init__(self, p: NSParams, slab: Slab, backend, device, ld: int, vprof, overlap=False):
+    def __init__(self, p: NSParams, slab: Slab, backend, device, ld: int, vprof, overlap=False, schedule=None):
         self.p, self.slab, self.be, self.dev, self.ld = p, slab, backend, device, ld
         if slab.world > 1 and slab.halo < 4:
             # advect! needs reach + 1 <= halo - 1 valid rows and reach >= 2 (see step())
@@ -443,7 +522,7 @@ class SlabNavierStokes:
         self.Vprof = torch.as_tensor(vprof, dtype=torch.float64).to(device)
         if slab.iy0 == 0:
             self.Vy[0, :] = self.Vprof          # NavierStokes.jl:73
-        self.poisson = SlabPoisson(p, slab, backend, self.Pr, self.dP, self.divV, overlap=overlap)
+        self.poisson = SlabPoisson(p, slab, backend, self.Pr, self.dP, self.divV, overlap=overlap, schedule=schedule)
         self.hist = []
 
     def step(self) -> int:

@@ -26,7 +26,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, halo, overlap, nx, ny_loc, steps, niter, nchk, out):
+def _worker(rank, world, port, halo, schedule, nx, ny_loc, steps, niter, nchk, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -39,8 +39,8 @@ def _worker(rank, world, port, halo, overlap, nx, ny_loc, steps, niter, nchk, ou
         slab = make_slab(rank, world, ny_loc, halo)
         ld = _pitch(nx)
         ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
-        sim = SlabNavierStokes(p, slab, HipBackend(ctx, p, ld), dev, ld, init_vprof(p), overlap=overlap)
-        assert sim.poisson.overlap == overlap
+        sim = SlabNavierStokes(p, slab, HipBackend(ctx, p, ld), dev, ld, init_vprof(p), schedule=schedule)
+        assert sim.poisson.schedule == (schedule or "edges")
         iters = [sim.step() for _ in range(steps)]
         torch.cuda.synchronize()
         res = {k: sim.owned(k)[:, : {"Vx": nx + 1}.get(k, nx)].cpu() for k in ("Pr", "Vx", "Vy", "C", "dP")}
@@ -51,14 +51,18 @@ def _worker(rank, world, port, halo, overlap, nx, ny_loc, steps, niter, nchk, ou
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,halo,overlap,nx,ny_loc", [(2, 8, False, 45, 40), (2, 8, True, 45, 40),
-                                                         (3, 12, True, 54, 30), (3, 15, True, 54, 30)])
-def test_slab_time_steps_on_gpu(tmp_path, world, halo, overlap, nx, ny_loc):
-    """overlap=True: boundary bands run ahead on a second stream through a second library
-    context while the window is computed on the main stream; results must not change by a bit."""
+@pytest.mark.parametrize("world,halo,schedule,nx,ny_loc", [(2, 8, "plain", 45, 40), (2, 8, "bands", 45, 40),
+                                                          (3, 12, "bands", 54, 30), (3, 15, "bands", 54, 30),
+                                                          (2, 8, None, 45, 40), (3, 12, "edges", 54, 30),
+                                                          (3, 14, "edges", 70, 44), (4, 5, "edges", 33, 24)])
+def test_slab_time_steps_on_gpu(tmp_path, world, halo, schedule, nx, ny_loc):
+    """bands: boundary bands run ahead on a second stream through a second library context while
+    the window is computed on the main stream; edges (the default, None): the last launch of every
+    block produces the rows to be sent first, on a second stream, and leaves the halo rows to the
+    exchange.  Results must not change by a bit."""
     from oracle.ns_oracle import OracleSim
     steps, niter, nchk = 3, 400, 100
-    mp.spawn(_worker, args=(world, _free_port(), halo, overlap, nx, ny_loc, steps, niter, nchk, str(tmp_path)),
+    mp.spawn(_worker, args=(world, _free_port(), halo, schedule, nx, ny_loc, steps, niter, nchk, str(tmp_path)),
              nprocs=world, join=True)
     p = ns_params("NavierStokes", nx=nx, ny=ny_loc * world, niter=niter, nchk=nchk)
     ref = OracleSim(p)

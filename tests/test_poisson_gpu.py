@@ -290,3 +290,54 @@ def test_poisson_dense_arrays_staged(gpu, oracle, nx, ny):
             assert same_bits(gPr, Pr) and same_bits(gdP, dP), stage
     finally:
         gpu.set_option("poisson_stage", 1)
+
+
+@pytest.mark.parametrize("pitched", [True, False])
+def test_edges_first_entry_point(gpu, oracle, pitched):
+    """nsk_ns_poisson_iters_edges_first: the last launch produces the edge rows first (on a second
+    stream), the rows between them on the context's stream and the skipped rows not at all.  All
+    rows but the skipped ones equal nsk_ns_poisson_iters bit for bit, for every way the call can go:
+    cut launch, a single launch (nothing to cut: plain sequence), no interior rows, no edge rows,
+    dense arrays on staging copies; work queued on either stream afterwards sees finished rows."""
+    import torch
+    nx, nyg = 150, 140
+    p = ns_params("NavierStokes", nx=nx, ny=nyg)
+    rng = np.random.default_rng(31)
+    Pr0, dP0, dv = rng_field(rng, nx, nyg), rng_field(rng, nx - 2, nyg - 2), rng_field(rng, nx, nyg, 10.0)
+    lo, hi = 20, 120                                  # a window with halo rows on both sides
+    wPr, wdv, wdP = (np.asfortranarray(Pr0[:, lo:hi]), np.asfortranarray(dv[:, lo:hi]),
+                     np.asfortranarray(dP0[:, lo:hi - 2]))
+    nyw = hi - lo
+    edge = torch.cuda.Stream()
+    for count, skip_lo, e_lo, e_hi, skip_hi in [(12, 8, 8, 8, 8), (40, 8, 8, 8, 8), (1, 8, 8, 8, 8), (13, 0, 0, 10, 6),
+                                                (12, 5, 20, 0, 0), (12, 10, 40, 40, 10), (12, 0, 0, 0, 0), (7, 3, 1, 1, 3)]:
+        want_Pr, want_dP = run_gpu(gpu, p, wPr, wdP, wdv, count, 0, pitched, iy0=lo, nyg=nyg)
+        if pitched:
+            ld = _pitch(nx)
+            dPr, dDv = Dev(wPr, ld, pad_value=np.nan), Dev(wdv, ld, pad_value=np.nan)
+            emb = np.full((nx, nyw), np.nan, order="F")
+            emb[1:-1, 1:-1] = wdP
+            dDp = Dev(emb, ld, pad_value=np.nan)
+            cp = c_params(p, ld_pr=ld, dp_embedded=1, iy0=lo, nyg=nyg, ny=nyw)
+        else:
+            dPr, dDv, dDp = Dev(wPr), Dev(wdv), Dev(wdP)
+            cp = c_params(p, iy0=lo, nyg=nyg, ny=nyw)
+        gpu.ns_poisson_iters_edges_first(dPr.ptr, dDp.ptr, dDv.ptr, C.byref(cp), count, skip_lo, e_lo, e_hi, skip_hi,
+                                         C.c_void_p(edge.cuda_stream))
+        with torch.cuda.stream(edge):                 # ordered behind the edge rows only
+            e_rows = torch.cat([dPr.t[skip_lo:skip_lo + e_lo], dPr.t[nyw - skip_hi - e_hi:nyw - skip_hi]]).clone()
+        edge.synchronize()
+        got_Pr = dPr.get()
+        got_dP = dDp.get()
+        if pitched:
+            got_dP = np.asfortranarray(got_dP[1:-1, 1:-1])
+        a, b = skip_lo, nyw - skip_hi
+        assert same_bits(got_Pr[:, a:b], want_Pr[:, a:b]), (count, skip_lo, e_lo, e_hi, skip_hi)
+        pa, pb = max(a, 1), min(b, nyw - 1)
+        assert same_bits(got_dP[:, pa - 1:pb - 1], want_dP[:, pa - 1:pb - 1]), (count, skip_lo, e_lo, e_hi, skip_hi)
+        want_e = np.concatenate([want_Pr[:, a:a + e_lo], want_Pr[:, b - e_hi:b]], axis=1)
+        assert same_bits(e_rows.cpu().numpy().T[:nx], want_e), "edge rows as seen from the edge stream"
+    with pytest.raises(Exception, match="do not fit"):
+        gpu.ns_poisson_iters_edges_first(dPr.ptr, dDp.ptr, dDv.ptr, C.byref(cp), 6, 60, 10, 10, 60, C.c_void_p(edge.cuda_stream))
+    with pytest.raises(Exception, match="edge_stream is null"):
+        gpu.ns_poisson_iters_edges_first(dPr.ptr, dDp.ptr, dDv.ptr, C.byref(cp), 6, 1, 1, 1, 1, None)

@@ -45,13 +45,20 @@ def gathered(g, nx, nyg):
     return Pr, dP
 
 
-@pytest.mark.parametrize("world,ny_loc,halo,count", [(2, 40, 8, 8), (2, 40, 8, 27), (3, 30, 5, 23), (4, 16, 16, 40)])
-def test_copy_transport_matches_single_domain(gpu, oracle, world, ny_loc, halo, count):
+@pytest.mark.parametrize("edges_first", [1, 0])
+@pytest.mark.parametrize("world,ny_loc,halo,count", [(2, 40, 8, 8), (2, 40, 8, 27), (3, 30, 5, 23), (4, 16, 16, 40),
+                                                     (3, 40, 12, 60), (5, 30, 14, 31)])
+def test_copy_transport_matches_single_domain(gpu, oracle, world, ny_loc, halo, count, edges_first):
+    """edges_first (default): the last launch of each block of passes produces the rows to be sent
+    first, on a second stream, and skips the halo rows; 0: whole window, then the exchange."""
     nx, nyg = 70, world * ny_loc
     p = ns_params("NavierStokes", nx=nx, ny=nyg)
     Pr0, dP0, dv = fields(np.random.default_rng(world * 100 + count), nx, nyg)
     g = make_group(p, world, ny_loc, halo)
     try:
+        g.set_option("edges_first", edges_first)
+        with pytest.raises(_lib.NskError, match="unknown option"):
+            g.set_option("no_such_switch", 1)
         assert g.info() == {"world": world, "nlocal": world, "transport": 2, "exchanges": 0}
         for i in range(world):
             w = g.window(i)

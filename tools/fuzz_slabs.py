@@ -46,6 +46,7 @@ def sweep(oracle, cases, seed, verbose=True):
             dv = np.asfortranarray(rng.standard_normal((nx, nyg)) * 10.0)
             g = _lib.Slabs(world, 0, [0] * world, c_params(p), ny_loc, halo, transport=2)
             try:
+                g.set_option("edges_first", int(rng.integers(0, 2)))
                 for name, arr in (("Pr", Pr0), ("dPrdtau", dP0), ("divV", dv)):
                     g.upload(name, arr)
                 g.poisson_iters(count)

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Compute-side cost of the two slab schedules on ONE GPU: an interior rank (two neighbours) of a
+"""Compute-side cost of the slab schedules on ONE GPU: an interior rank (two neighbours) of a
 2559 x 4095-per-rank decomposition runs `passes` Poisson passes with its halo rows refilled by
 device copies instead of peers (loopback), so everything but the wire is timed: redundant halo
-rows, the boundary bands of the overlapped schedule and how they disturb the window's launches,
-the install copies.  Prints us per pass against the single-domain loop.
+rows, the cut last launch of the edges-first schedule, the boundary bands of the bands schedule
+and how they disturb the window's launches, the install copies.  With a wire time (us) a spin
+kernel of that length stands where the transfer would run, which shows what each schedule hides.
+Prints us per pass against the single-domain loop.
 
-  python tools/overlap_overhead.py [passes]"""
+  python tools/overlap_overhead.py [passes] [wire_us] [halo:schedule ...]    schedule p | e | b"""
 import os
 import sys
 import time
@@ -18,12 +20,28 @@ from navierstokes_amd.dist import HipBackend, SlabPoisson, make_slab
 from navierstokes_amd.ns import _pitch
 
 
-def run(p, halo, overlap, passes, world=3, rank=1):
+def spin_cycles(us):
+    """torch.cuda._sleep cycles for `us` microseconds (calibrated on the spot)."""
+    if us <= 0:
+        return 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 10_000_000
+    torch.cuda._sleep(n)
+    torch.cuda.synchronize()
+    e0.record()
+    torch.cuda._sleep(n)
+    e1.record()
+    torch.cuda.synchronize()
+    return int(n * us / (e0.elapsed_time(e1) * 1e3))
+
+
+def run(p, halo, schedule, passes, world=3, rank=1, wire=0):
     dev = torch.device("cuda", 0)
     slab = make_slab(rank, world, p.ny, halo)
     pg = p.with_(ny=p.ny * world, ly=p.ly * world) if world > 1 else p
     ld = _pitch(p.nx)
     ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    ctx.set_option("poisson_edge_task_rows", int(os.environ.get("NSK_EDGE_TASK_ROWS", "0")))
     g = torch.Generator(device="cpu").manual_seed(7)
     def rnd():
         t = torch.zeros((slab.ny_win, ld), dtype=torch.float64)
@@ -31,13 +49,14 @@ def run(p, halo, overlap, passes, world=3, rank=1):
         return t.to(dev)
     Pr, divV = rnd(), rnd()
     dP = torch.zeros_like(Pr)
-    sp = SlabPoisson(pg, slab, HipBackend(ctx, pg, ld), Pr, dP, divV, overlap=overlap)
+    sp = SlabPoisson(pg, slab, HipBackend(ctx, pg, ld), Pr, dP, divV, schedule=schedule)
     sp.loopback = True
+    sp.loopback_wire = wire
     sp.iterate(2 * max(halo, 6))
     sp.timing = True
     if os.environ.get("NSK_DEBUG_POLL"):
         streams = {"main": torch.cuda.current_stream()}
-        if sp.overlap:
+        if sp.schedule == "bands":
             streams.update(band=sp.band_stream, comm=sp.comm_stream)
         for i in range(8):
             state = {k: v.query() for k, v in streams.items()}
@@ -61,16 +80,20 @@ def main():
     import faulthandler
     faulthandler.dump_traceback_later(45, exit=True)     # a stuck run says where and ends
     passes = int(sys.argv[1]) if len(sys.argv) > 1 else 2400
-    cases = [(60, False), (120, False), (24, True), (36, True), (60, True)]
-    if len(sys.argv) > 2:
-        cases = [(int(h), o == "o") for h, o in (c.split(":") for c in sys.argv[2:])]
+    wire_us = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+    cases = [(60, "plain"), (60, "edges"), (120, "plain"), (120, "edges"), (24, "bands")]
+    if len(sys.argv) > 3:
+        names = {"p": "plain", "e": "edges", "b": "bands"}
+        cases = [(int(h), names[o]) for h, o in (c.split(":") for c in sys.argv[3:])]
     p = ns_params("NavierStokes_Re6", n=16)
-    base, _ = run(p, 0, False, passes, world=1, rank=0)
-    print(f"single domain                       {base:7.2f} us/pass", flush=True)
-    for halo, overlap in cases:
+    torch.cuda.set_device(0)
+    wire = spin_cycles(wire_us)
+    base, _ = run(p, 0, "plain", passes, world=1, rank=0)
+    print(f"single domain                       {base:7.2f} us/pass   (stand-in for the transfer: {wire_us:.0f} us per exchange)", flush=True)
+    for halo, schedule in cases:
         faulthandler.dump_traceback_later(45, exit=True)
-        t, ex = run(p, halo, overlap, passes)
-        print(f"halo {halo:3d} {'overlapped' if overlap else 'plain     '}  {t:7.2f} us/pass  "
+        t, ex = run(p, halo, schedule, passes, wire=wire)
+        print(f"halo {halo:3d} {schedule:6s}  {t:7.2f} us/pass  "
               f"{(t / base - 1) * 100:5.1f} % over single domain, {ex:6.1f} us per exchange after the last pass", flush=True)
 
 
