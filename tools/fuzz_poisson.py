@@ -7,7 +7,8 @@ infrastructure; tests/test_poisson_fuzz_gpu.py runs a few hundred cases of it, t
 Each case draws a grid (including the degenerate 3-wide ones and sizes around the 116/128-column
 strip and the chunk heights), the storage form, the passes per launch K, the task height, the edge
 strip percentage, XCD numbering on/off, the bc_x! row rule, a pass count, optionally a slab window of
-a taller grid, and a data scale (ordinary, tiny, huge, with exact zeros).  Values are compared as
+a taller grid, a data scale (ordinary, tiny, huge, with exact zeros), and whether the call goes
+through nsk_ns_poisson_iters_edges_first with random edge and skipped rows.  Values are compared as
 bit patterns: signed zeros must agree as well, only NaN payloads are not compared."""
 import argparse
 import ctypes as C
@@ -44,6 +45,7 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
     a = argparse.Namespace(cases=cases, seed=seed, max_n=max_n)
     rng = np.random.default_rng(a.seed)
     failures = []
+    edge_stream = torch.cuda.Stream()
     interesting = [3, 4, 5, 6, 7, 113, 114, 115, 116, 117, 118, 119, 127, 128, 129, 130, 231, 232, 233, 234, 255, 256, 257]
     t_start, bad = time.time(), 0
     for case in range(a.cases):
@@ -102,29 +104,47 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
         else:
             dPr, dDv, dDp = Dev(wPr), Dev(wdv), Dev(wdP)
             cp = c_params(p.with_(full_rows=bool(full)), iy0=lo, nyg=nyg, ny=nyw)
-        ctx.ns_poisson_iters(dPr.ptr, dDp.ptr, dDv.ptr, C.byref(cp), count)
+        # sometimes through the edges-first entry point: random edge and skipped rows at both ends
+        sk_lo = sk_hi = 0
+        ef = None
+        if rng.random() < 0.35 and nyw >= 8:
+            cut = sorted(int(x) for x in rng.integers(0, nyw // 2, 2))
+            sk_lo, e_lo = (cut[0], cut[1] - cut[0]) if lo > 0 else (0, int(rng.integers(0, nyw // 2)))
+            cut = sorted(int(x) for x in rng.integers(0, nyw // 2, 2))
+            sk_hi, e_hi = (cut[0], cut[1] - cut[0]) if hi < nyg else (0, int(rng.integers(0, nyw // 2)))
+            ef = (sk_lo, e_lo, e_hi, sk_hi)
+            ctx.set_option("poisson_edge_task_rows", int(rng.choice([0, 0, 2, 3, 12])))
+            ctx.ns_poisson_iters_edges_first(dPr.ptr, dDp.ptr, dDv.ptr, C.byref(cp), count, sk_lo, e_lo, e_hi, sk_hi,
+                                             C.c_void_p(edge_stream.cuda_stream))
+            edge_stream.synchronize()
+        else:
+            ctx.ns_poisson_iters(dPr.ptr, dDp.ptr, dDv.ptr, C.byref(cp), count)
         gPr = dPr.get()
         gdP = dDp.get()
         if pitched:
             gdP = np.asfortranarray(gdP[1:-1, 1:-1])
         a0 = 0 if lo == 0 else count
         b0 = nyw if hi == nyg else nyw - count
+        a0, b0 = max(a0, sk_lo), min(b0, nyw - sk_hi)     # skipped rows hold undefined values
+        if b0 <= a0:
+            continue
         ok = strict_same(gPr[:, a0:b0], Pr[:, lo + a0:lo + b0])
         pa, pb = max(a0, 1), min(b0, nyw - 1)
         ok = ok and strict_same(gdP[:, pa - 1:pb - 1], dP[:, lo + pa - 1:lo + pb - 1])
-        if lo > 0:
+        if lo > 0 and sk_lo == 0:
             ok = ok and strict_same(gPr[:, 0], wPr[:, 0])
-        if hi < nyg:
+        if hi < nyg and sk_hi == 0:
             ok = ok and strict_same(gPr[:, -1], wPr[:, -1])
         desc = (f"case {case}: nx={nx} nyg={nyg} window=[{lo},{hi}) pitched={pitched} K={K}->{ctx.get_option('poisson_k')} rows={rows} "
-                f"edge={edge} xcd={xcd} full={full} count={count} scale={scale} zeros={zero_frac} div={ctx.get_option('poisson_div_used')}")
+                f"edge={edge} xcd={xcd} full={full} count={count} scale={scale} zeros={zero_frac} div={ctx.get_option('poisson_div_used')} "
+                f"edges_first={ef}")
         if not ok:
             bad += 1
             failures.append(desc)
             print("MISMATCH", desc, flush=True)
         elif verbose and case % 25 == 0:
             print("ok", desc, f"[{time.time() - t_start:.0f} s]", flush=True)
-    for opt in ("poisson_k", "poisson_rows", "poisson_edge_percent"):
+    for opt in ("poisson_k", "poisson_rows", "poisson_edge_percent", "poisson_edge_task_rows"):
         ctx.set_option(opt, 0)
     ctx.set_option("poisson_xcd", 1)
     if verbose:
