@@ -410,6 +410,38 @@ int nsk_bub_regrid_front(nsk_ctx *ctx, double *xf, double *yf, double *xscratch,
                          double *yscratch, double dx, double dy, int Nf, int cap,
                          int *Nf_out);
 
+/* Whole time steps of the two bubble drivers: the kernels above in the drivers' order, queued in
+ * one call with a single wait at the end for the sweep counts (the reference reads every count
+ * back, and scripts/DNS.jl:83-93 synchronises per sweep).  Same values as the kernel-by-kernel
+ * sequence.  Scalars of scripts/DNS.jl:16-45 and scripts/code3_fun.jl:296-309,337,340; the DNS
+ * driver uses m1 as its one viscosity (m0) and ignores m2, sigma, rro. */
+typedef struct nsk_bub_params {
+  int nx, ny, maxit;
+  double Lx, Ly, gx, gy, rho1, rho2, m1, m2, sigma, rro, usouth, unorth, vwest, veast;
+  double dt, dx, dy, maxError, beta;
+} nsk_bub_params;
+/* device arrays of scripts/DNS.jl:52-62: u (nx+1, ny+2), v (nx+2, ny+1), uu, vv (nx+1, ny+1),
+ * the others (nx+2, ny+2); r = rho, ro = its copy before advect_density!, rt = rhot */
+typedef struct nsk_bub_dns_state {
+  double *u, *v, *p, *ut, *vt, *tmp1, *tmp2, *r, *ro, *rt, *uu, *vv;
+} nsk_bub_dns_state;
+/* device arrays of scripts/code3_fun.jl:311-327,345-352: grid arrays as above (un, vn, rn, mn =
+ * the copies of :357-362), front vectors of `cap` points (xs, ys: scratch of the regridding),
+ * Nf = points of the front (updated by the step) */
+typedef struct nsk_bub_code3_state {
+  double *u, *v, *p, *ut, *vt, *tmp1, *tmp2, *fx, *fy, *un, *vn, *r, *m, *rn, *mn, *rt;
+  double *xf, *yf, *xfn, *yfn, *uf, *vf, *tx, *ty, *xs, *ys;
+  int Nf, cap;
+} nsk_bub_code3_state;
+/* scripts/DNS.jl:71-101 (form of scripts/code1.m:33-96) with the lexicographic SOR;
+ * *sweeps_out = sweeps of the pressure solve (may be NULL: then the call does not wait). */
+int nsk_bub_dns_step(nsk_ctx *ctx, const nsk_bub_dns_state *s, const nsk_bub_params *q,
+                     int *sweeps_out);
+/* scripts/code3_fun.jl:356-494; sweeps_out[0..3] = pressure and density sweeps of the two substeps
+ * (may be NULL); s->Nf receives the regridded front size.  Synchronous. */
+int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const nsk_bub_params *q,
+                       int *sweeps_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -252,6 +252,39 @@ function info(s::Slabs)
     (; world=v[1][], nlocal=v[2][], transport=v[3][], exchanges=v[4][])
 end
 
+# struct nsk_bub_params / nsk_bub_dns_state / nsk_bub_code3_state, field for field
+struct BubParams
+    nx::Cint; ny::Cint; maxit::Cint
+    Lx::Cdouble; Ly::Cdouble; gx::Cdouble; gy::Cdouble; rho1::Cdouble; rho2::Cdouble; m1::Cdouble; m2::Cdouble
+    sigma::Cdouble; rro::Cdouble; usouth::Cdouble; unorth::Cdouble; vwest::Cdouble; veast::Cdouble
+    dt::Cdouble; dx::Cdouble; dy::Cdouble; maxError::Cdouble; beta::Cdouble
+end
+struct DnsState
+    u::Ptr{Cdouble}; v::Ptr{Cdouble}; p::Ptr{Cdouble}; ut::Ptr{Cdouble}; vt::Ptr{Cdouble}; tmp1::Ptr{Cdouble}
+    tmp2::Ptr{Cdouble}; r::Ptr{Cdouble}; ro::Ptr{Cdouble}; rt::Ptr{Cdouble}; uu::Ptr{Cdouble}; vv::Ptr{Cdouble}
+end
+struct Code3State
+    u::Ptr{Cdouble}; v::Ptr{Cdouble}; p::Ptr{Cdouble}; ut::Ptr{Cdouble}; vt::Ptr{Cdouble}; tmp1::Ptr{Cdouble}
+    tmp2::Ptr{Cdouble}; fx::Ptr{Cdouble}; fy::Ptr{Cdouble}; un::Ptr{Cdouble}; vn::Ptr{Cdouble}; r::Ptr{Cdouble}
+    m::Ptr{Cdouble}; rn::Ptr{Cdouble}; mn::Ptr{Cdouble}; rt::Ptr{Cdouble}
+    xf::Ptr{Cdouble}; yf::Ptr{Cdouble}; xfn::Ptr{Cdouble}; yfn::Ptr{Cdouble}; uf::Ptr{Cdouble}; vf::Ptr{Cdouble}
+    tx::Ptr{Cdouble}; ty::Ptr{Cdouble}; xs::Ptr{Cdouble}; ys::Ptr{Cdouble}
+    Nf::Cint; cap::Cint
+end
+"One time step of DNS.jl:71-101 in one call; returns the sweeps of the pressure solve."
+function dns_step!(c, s::DnsState, q::BubParams)
+    sw = Ref{Cint}(0)
+    check(ccall((:nsk_bub_dns_step, lib), Cint, (Ptr{Cvoid}, Ref{DnsState}, Ref{BubParams}, Ptr{Cint}), c.h, s, q, sw))
+    sw[]
+end
+"One time step of code3_fun.jl:356-494 in one call; returns the state with the new front size and the four sweep counts."
+function code3_step!(c, s::Code3State, q::BubParams)
+    r = Ref(s)
+    sw = zeros(Cint, 4)
+    check(ccall((:nsk_bub_code3_step, lib), Cint, (Ptr{Cvoid}, Ref{Code3State}, Ref{BubParams}, Ptr{Cint}), c.h, r, q, sw))
+    r[], sw
+end
+
 # ---- bubble / drop solvers: scripts/DNS.jl (in the form scripts/code1.m states) and ----------
 # ---- scripts/code3_fun.jl; one stub per kernel, argument order of the Julia kernels ----------
 vec(c::Ctx, n) = zeros(c, n, 1)

@@ -40,6 +40,25 @@ class CNSState(C.Structure):
         "divV", "Rp", "Vprof")]
 
 
+class CBubParams(C.Structure):
+    """struct nsk_bub_params (include/nsk.h)."""
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("maxit", C.c_int)] + \
+               [(n, C.c_double) for n in ("Lx", "Ly", "gx", "gy", "rho1", "rho2", "m1", "m2", "sigma", "rro", "usouth",
+                                          "unorth", "vwest", "veast", "dt", "dx", "dy", "maxError", "beta")]
+
+
+class CDnsState(C.Structure):
+    """struct nsk_bub_dns_state (include/nsk.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("u", "v", "p", "ut", "vt", "tmp1", "tmp2", "r", "ro", "rt", "uu", "vv")]
+
+
+class CCode3State(C.Structure):
+    """struct nsk_bub_code3_state (include/nsk.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("u", "v", "p", "ut", "vt", "tmp1", "tmp2", "fx", "fy", "un", "vn", "r", "m",
+                                          "rn", "mn", "rt", "xf", "yf", "xfn", "yfn", "uf", "vf", "tx", "ty", "xs", "ys")] + \
+               [("Nf", C.c_int), ("cap", C.c_int)]
+
+
 _D, _I, _P, _S = C.c_double, C.c_int, C.c_void_p, C.c_size_t
 
 # name -> argtypes (after the leading context pointer); all return int
@@ -90,6 +109,8 @@ _SIGS = {
     "nsk_bub_average": [_P, _P, _S],
     "nsk_bub_regrid_front": [_P, _P, _P, _P, _D, _D, _I, _I, c_int_p],
     "nsk_ns_poisson_iters": [_P, _P, _P, C.POINTER(CNSParams), _I],
+    "nsk_bub_dns_step": [C.POINTER(CDnsState), C.POINTER(CBubParams), C.POINTER(C.c_int)],
+    "nsk_bub_code3_step": [C.POINTER(CCode3State), C.POINTER(CBubParams), C.POINTER(C.c_int)],
     "nsk_ns_poisson_iters_static": [_P, _P, _P, C.POINTER(CNSParams), _I],
     "nsk_ns_poisson_iters_edges_first": [_P, _P, _P, C.POINTER(CNSParams), _I, _I, _I, _I, _I, _P],
     "nsk_ns_residual": [_P, _P, _P, C.POINTER(CNSParams), _I, _I, c_double_p],

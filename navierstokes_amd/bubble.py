@@ -123,11 +123,25 @@ class DNS:
                                  q.rad, q.rho2, 0.0, nx, ny)
         self.time = 0.0
         self.sweeps = 0
+        # True: one C call per time step (nsk_bub_dns_step: the same kernels, one wait per step);
+        # False: one C call per kernel, as the reference's driver is written
+        self.fused = True
 
     def step(self) -> int:
         """DNS.jl:71-101."""
         q, k, nx, ny = self.q, self.ctx, self.q.nx, self.q.ny
         self.time += q.dt
+        if self.fused and q.pressure_solver == "sor":
+            st = _lib.CDnsState(u=self.u.ptr, v=self.v.ptr, p=self.p.ptr, ut=self.ut.ptr, vt=self.vt.ptr,
+                                tmp1=self.tmp1.ptr, tmp2=self.tmp2.ptr, r=self.rho.ptr, ro=self.rho_o.ptr,
+                                rt=self.rhot.ptr, uu=self.uu.ptr, vv=self.vv.ptr)
+            pr = _lib.CBubParams(nx=nx, ny=ny, maxit=q.maxit, Lx=q.Lx, Ly=q.Ly, gx=q.gx, gy=q.gy, rho1=q.rho1,
+                                 rho2=q.rho2, m1=q.m0, m2=0.0, sigma=0.0, rro=0.0, usouth=q.usouth, unorth=q.unorth,
+                                 vwest=q.vwest, veast=q.veast, dt=q.dt, dx=q.dx, dy=q.dy, maxError=q.maxerr, beta=q.beta)
+            sw = C.c_int(0)
+            k.bub_dns_step(C.byref(st), C.byref(pr), C.byref(sw))
+            self.sweeps = sw.value
+            return sw.value
         k.bub_set_tangential(self.u.ptr, self.v.ptr, q.usouth, q.unorth, q.vwest, q.veast, nx, ny)
         k.bub_temp_vel(self.ut.ptr, self.vt.ptr, self.u.ptr, self.v.ptr, self.rho.ptr, q.dt, q.dx, q.dy,
                        q.gx, q.gy, q.m0, nx, ny)
@@ -257,11 +271,24 @@ class Code3:
         self.Nf = q.Nf
         self.time = 0.0
         self.sweeps = [0, 0, 0, 0]
+        self.fused = True            # one C call per time step (nsk_bub_code3_step) / one per kernel
 
     def step(self):
         """code3_fun.jl:356-494."""
         q, k, nx, ny = self.q, self.ctx, self.q.nx, self.q.ny
         dt, dx, dy = q.dt, q.dx, q.dy
+        if self.fused:
+            st = _lib.CCode3State(**{n: getattr(self, n).ptr for n in self.GRID + self.FRONT}, Nf=self.Nf, cap=q.cap)
+            pr = _lib.CBubParams(nx=nx, ny=ny, maxit=q.maxit, Lx=q.Lx, Ly=q.Ly, gx=q.gx, gy=q.gy, rho1=q.rho1,
+                                 rho2=q.rho2, m1=q.m1, m2=q.m2, sigma=q.sigma, rro=q.rro, usouth=q.usouth,
+                                 unorth=q.unorth, vwest=q.vwest, veast=q.veast, dt=dt, dx=dx, dy=dy,
+                                 maxError=q.maxError, beta=q.beta)
+            sw = (C.c_int * 4)()
+            k.bub_code3_step(C.byref(st), C.byref(pr), sw)
+            self.Nf = st.Nf
+            self.time += dt
+            self.sweeps = list(sw)
+            return self.sweeps
         for a, b in (("un", "u"), ("vn", "v"), ("rn", "r"), ("mn", "m"), ("xfn", "xf"), ("yfn", "yf")):
             getattr(self, a).copy_from(getattr(self, b))
         sw = [0, 0, 0, 0]

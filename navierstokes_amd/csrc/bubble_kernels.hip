@@ -616,11 +616,13 @@ __global__ void __launch_bounds__(64) k_regrid_front(dp xf, dp yf, dp xo, dp yo,
   *Nf_io = Nn;
 }
 
+// dev_sweeps: device word that receives the sweep count instead of the default slot (the fused
+// steps read all their counters back once, at the end).
 int launch_sor(nsk_ctx *ctx, int mode, double *a, const double *c1, const double *c2,
                const double *c3, double beta, double dx, double dy, int nx, int ny, int maxit,
-               double maxError, int *sweeps, double *change) {
-  // device-side result slots live in the context's reduction scratch (64 bytes)
-  int *d_sweeps = reinterpret_cast<int *>(ctx->red_dev + 2);
+               double maxError, int *sweeps, double *change, int *dev_sweeps = nullptr) {
+  // device-side result slots live in the context's reduction scratch
+  int *d_sweeps = dev_sweeps ? dev_sweeps : reinterpret_cast<int *>(ctx->red_dev + 2);
   double *d_change = reinterpret_cast<double *>(ctx->red_dev + 3);
   SorArgs A{a, c1, c2, c3, beta, dx, dy, maxError, nx, ny, maxit, d_sweeps, d_change};
   const size_t bytes = sizeof(double) * (size_t)(nx + 2) * (ny + 2);
@@ -914,5 +916,99 @@ extern "C" int nsk_bub_regrid_front(nsk_ctx *ctx, double *xf, double *yf, double
   NSK_HIP(hipStreamSynchronize(ctx->stream));
   *Nf_out = *reinterpret_cast<int *>(ctx->red_host + 5);
   NSK_REQUIRE(*Nf_out >= 0, "regrid_front: the front outgrew its capacity of %d points", cap);
+  return 0;
+}
+
+// ---- whole time steps --------------------------------------------------------------------------
+// The reference's drivers call one kernel after the other and read the sweep count of every
+// pressure solve back on the host (DNS.jl:83-93 even synchronises per sweep).  These two entry
+// points queue a whole time step and wait once, at its end, for the sweep counts (and the new front
+// size): same kernels, same order, same values as the kernel-by-kernel sequence.
+namespace {
+// words 8.. of the context's reduction scratch: sweep counts of the step's solves, then the front size
+inline int *step_word(nsk_ctx *ctx, int k) { return reinterpret_cast<int *>(ctx->red_dev + 8 + k); }
+inline int host_word(nsk_ctx *ctx, int k) { return *reinterpret_cast<int *>(ctx->red_host + 8 + k); }
+}  // namespace
+
+// DNS.jl:71-101 (in the form code1.m:33-96 intends) with the lexicographic SOR.
+extern "C" int nsk_bub_dns_step(nsk_ctx *ctx, const nsk_bub_dns_state *s, const nsk_bub_params *q, int *sweeps_out) {
+  NSK_CTX(ctx);
+  NSK_REQUIRE(s != nullptr && q != nullptr, "nsk_bub_dns_step: null argument");
+  NSK_NONNULL(s->u, s->v, s->p, s->ut, s->vt, s->tmp1, s->tmp2, s->r, s->ro, s->rt, s->uu, s->vv);
+  const int nx = q->nx, ny = q->ny;
+  NSK_BGRID_OK(nx, ny);
+  if (int rc = nsk_bub_set_tangential(ctx, s->u, s->v, q->usouth, q->unorth, q->vwest, q->veast, nx, ny)) return rc;
+  if (int rc = nsk_bub_temp_vel(ctx, s->ut, s->vt, s->u, s->v, s->r, q->dt, q->dx, q->dy, q->gx, q->gy, q->m1, nx, ny)) return rc;
+  if (int rc = nsk_bub_set_boundary(ctx, s->rt, s->r, 1000.0, nx, ny)) return rc;
+  if (int rc = nsk_bub_compute_sources(ctx, s->tmp1, s->tmp2, s->rt, s->ut, s->vt, q->dt, q->dx, q->dy, nx, ny)) return rc;
+  if (int rc = launch_sor(ctx, 0, s->p, s->tmp1, s->tmp2, s->rt, q->beta, q->dx, q->dy, nx, ny, q->maxit, q->maxError,
+                          nullptr, nullptr, step_word(ctx, 0)))
+    return rc;
+  if (int rc = nsk_bub_correct_vel(ctx, s->u, s->v, s->ut, s->vt, s->p, s->r, q->dt, q->dx, q->dy, nx, ny)) return rc;
+  NSK_HIP(hipMemcpyAsync(s->ro, s->r, sizeof(double) * (size_t)(nx + 2) * (ny + 2), hipMemcpyDeviceToDevice, ctx->stream));
+  if (int rc = nsk_bub_advect_density(ctx, s->r, s->ro, s->u, s->v, q->dt, q->dx, q->dy, q->m1, nx, ny)) return rc;
+  if (int rc = nsk_bub_velocity(ctx, s->uu, s->vv, s->u, s->v, nx, ny)) return rc;
+  if (sweeps_out) {
+    NSK_HIP(hipMemcpyAsync(ctx->red_host + 8, ctx->red_dev + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+    NSK_HIP(hipStreamSynchronize(ctx->stream));
+    *sweeps_out = host_word(ctx, 0);
+  }
+  return 0;
+}
+
+// code3_fun.jl:356-494: two substeps, second-order averaging, regridding of the front.  s->Nf is
+// updated; sweeps_out[0..3] = pressure and density sweeps of the two substeps.
+extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const nsk_bub_params *q, int *sweeps_out) {
+  NSK_CTX(ctx);
+  NSK_REQUIRE(s != nullptr && q != nullptr, "nsk_bub_code3_step: null argument");
+  NSK_NONNULL(s->u, s->v, s->p, s->ut, s->vt, s->tmp1, s->tmp2, s->fx, s->fy, s->un, s->vn, s->r, s->m, s->rn, s->mn, s->rt);
+  NSK_NONNULL(s->xf, s->yf, s->xfn, s->yfn, s->uf, s->vf, s->tx, s->ty, s->xs, s->ys);
+  const int nx = q->nx, ny = q->ny, Nf = s->Nf;
+  NSK_BGRID_OK(nx, ny);
+  NSK_REQUIRE(Nf >= 1 && s->cap >= Nf + 2, "nsk_bub_code3_step: front of %d points in vectors of %d", Nf, s->cap);
+  const size_t w = sizeof(double), nu = (size_t)(nx + 1) * (ny + 2), nv = (size_t)(nx + 2) * (ny + 1),
+               nc = (size_t)(nx + 2) * (ny + 2), nf = (size_t)Nf + 2;
+  struct { double *to; const double *from; size_t n; } keep[] = {{s->un, s->u, nu}, {s->vn, s->v, nv}, {s->rn, s->r, nc},
+                                                                 {s->mn, s->m, nc}, {s->xfn, s->xf, (size_t)s->cap},
+                                                                 {s->yfn, s->yf, (size_t)s->cap}};
+  for (auto &k : keep) NSK_HIP(hipMemcpyAsync(k.to, k.from, k.n * w, hipMemcpyDeviceToDevice, ctx->stream));
+  for (int sub = 0; sub < 2; sub++) {
+    if (int rc = nsk_bub_surface_tension(ctx, s->fx, s->fy, s->tx, s->ty, s->xf, s->yf, q->sigma, q->dx, q->dy, nx, ny, Nf)) return rc;
+    if (int rc = nsk_bub_set_tangential(ctx, s->u, s->v, q->usouth, q->unorth, q->vwest, q->veast, nx, ny)) return rc;
+    if (int rc = nsk_bub_temp_vel_adv(ctx, s->ut, s->vt, s->u, s->v, s->r, q->dt, q->dx, q->dy, s->fx, s->fy, q->gx, q->gy, q->rro, nx, ny)) return rc;
+    if (int rc = nsk_bub_temp_vel_diff(ctx, s->ut, s->vt, s->u, s->v, s->r, q->dt, q->dx, q->dy, s->m, nx, ny)) return rc;
+    if (int rc = nsk_bub_set_boundary(ctx, s->rt, s->r, 1000.0, nx, ny)) return rc;
+    if (int rc = nsk_bub_compute_sources(ctx, s->tmp1, s->tmp2, s->rt, s->ut, s->vt, q->dt, q->dx, q->dy, nx, ny)) return rc;
+    if (int rc = launch_sor(ctx, 0, s->p, s->tmp1, s->tmp2, s->rt, q->beta, q->dx, q->dy, nx, ny, q->maxit, q->maxError,
+                            nullptr, nullptr, step_word(ctx, 2 * sub)))
+      return rc;
+    if (int rc = nsk_bub_correct_vel(ctx, s->u, s->v, s->ut, s->vt, s->p, s->r, q->dt, q->dx, q->dy, nx, ny)) return rc;
+    if (int rc = nsk_bub_advect_move_front(ctx, s->uf, s->vf, s->xf, s->yf, s->u, s->v, q->dx, q->dy, q->dt, q->Lx, q->Ly, nx, ny, Nf, nullptr)) return rc;
+    if (int rc = nsk_bub_distribute(ctx, s->fx, s->fy, s->xf, s->yf, q->rho1, q->rho2, q->dx, q->dy, nx, ny, Nf)) return rc;
+    if (int rc = launch_sor(ctx, 1, s->r, s->fx, s->fy, nullptr, q->beta, q->dx, q->dy, nx, ny, q->maxit, q->maxError,
+                            nullptr, nullptr, step_word(ctx, 2 * sub + 1)))
+      return rc;
+    if (int rc = nsk_bub_update_visco(ctx, s->r, s->m, q->m1, q->m2, q->rho1, q->rho2, nx, ny)) return rc;
+  }
+  // second-order averaging, code3_fun.jl:445-450
+  if (int rc = nsk_bub_average(ctx, s->u, s->un, nu)) return rc;
+  if (int rc = nsk_bub_average(ctx, s->v, s->vn, nv)) return rc;
+  if (int rc = nsk_bub_average(ctx, s->r, s->rn, nc)) return rc;
+  if (int rc = nsk_bub_average(ctx, s->m, s->mn, nc)) return rc;
+  if (int rc = nsk_bub_average(ctx, s->xf, s->xfn, nf)) return rc;
+  if (int rc = nsk_bub_average(ctx, s->yf, s->yfn, nf)) return rc;
+  // regridding, :455-494; the front size travels with the sweep counts
+  int *d_nf = step_word(ctx, 4);
+  *reinterpret_cast<int *>(ctx->red_host + 16) = Nf;
+  NSK_HIP(hipMemcpyAsync(d_nf, ctx->red_host + 16, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  k_regrid_front<<<1, 64, 0, ctx->stream>>>(s->xf, s->yf, s->xs, s->ys, q->dx, q->dy, d_nf, s->cap);
+  NSK_LAUNCH_CHECK();
+  NSK_HIP(hipMemcpyAsync(ctx->red_host + 8, ctx->red_dev + 8, 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  NSK_HIP(hipStreamSynchronize(ctx->stream));
+  const int nf_new = host_word(ctx, 4);
+  NSK_REQUIRE(nf_new >= 0, "nsk_bub_code3_step: the front outgrew its capacity of %d points", s->cap);
+  s->Nf = nf_new;
+  if (sweeps_out)
+    for (int k = 0; k < 4; k++) sweeps_out[k] = host_word(ctx, k);
   return 0;
 }

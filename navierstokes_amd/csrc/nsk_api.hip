@@ -37,8 +37,8 @@ extern "C" int nsk_create(int device, nsk_ctx **out) {
     return 1;
   }
   c->stream = c->own_stream;
-  if (hipMalloc(&c->red_dev, 64) != hipSuccess ||
-      hipHostMalloc(&c->red_host, 64, hipHostMallocDefault) != hipSuccess) {
+  if (hipMalloc(&c->red_dev, 256) != hipSuccess ||
+      hipHostMalloc(&c->red_host, 256, hipHostMallocDefault) != hipSuccess) {
     nsk_set_error("nsk_create: scratch allocation failed");
     nsk_destroy(c);
     return 1;

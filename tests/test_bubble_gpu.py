@@ -163,10 +163,13 @@ def test_front_kernels(gpu, bo, nx, ny, Nf):
     assert same_bits(dxf.get()[: n2 + 2, 0], xo[: n2 + 2]) and same_bits(dyf.get()[: n2 + 2, 0], yo[: n2 + 2])
 
 
-def test_dns_steps():
-    """scripts/DNS.jl at its sizes (32 x 32, dt .00125, beta 1.2, maxit 400): 25 steps."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_dns_steps(fused):
+    """scripts/DNS.jl at its sizes (32 x 32, dt .00125, beta 1.2, maxit 400): 25 steps, as one C call
+    per time step (nsk_bub_dns_step) and as one call per kernel."""
     q = DNSParams()
     g, o = DNS(q), OracleDNS(q)
+    g.fused = fused
     for _ in range(25):
         assert g.step() == o.step()
     for k in ("rho", "u", "v", "p", "uu", "vv"):
@@ -273,10 +276,13 @@ def test_dns_steps_other_solvers(solver):
         assert same_bits(getattr(g, k).get(), getattr(o, k)), k
 
 
-def test_code3_steps():
-    """scripts/code3_fun.jl at its sizes (32 x 32, Nf = 100): 12 steps incl. front regridding."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_code3_steps(fused):
+    """scripts/code3_fun.jl at its sizes (32 x 32, Nf = 100): 12 steps incl. front regridding, as one C
+    call per time step (nsk_bub_code3_step) and as one call per kernel."""
     q = Code3Params()
     g, o = Code3(q), OracleCode3(q)
+    g.fused = fused
     for _ in range(12):
         assert g.step() == o.step()
         assert g.Nf == o.Nf
@@ -285,3 +291,20 @@ def test_code3_steps():
     gx, gy = g.front()
     ox, oy = o.front()
     assert same_bits(gx, ox) and same_bits(gy, oy)
+
+
+def test_fused_steps_report_their_errors(gpu):
+    """Null arrays, a front that does not fit its vectors and a front that outgrows them are errors of
+    the whole-step entry points, not faults."""
+    from navierstokes_amd import _lib
+    with pytest.raises(_lib.NskError, match="null"):
+        gpu.bub_dns_step(C.byref(_lib.CDnsState()), C.byref(_lib.CBubParams(nx=8, ny=8, maxit=3)), None)
+    q = Code3Params(nx=16, ny=16, Nf=60, cap=64)
+    g = Code3(q)
+    g.Nf = 63
+    with pytest.raises(_lib.NskError, match="front of 63 points in vectors of 64"):
+        g.step()
+    g = Code3(Code3Params(nx=48, ny=48, Nf=40, cap=48))      # coarse front on a fine grid: regridding doubles it
+    with pytest.raises(_lib.NskError, match="outgrew its capacity"):
+        for _ in range(3):
+            g.step()

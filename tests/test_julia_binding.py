@@ -46,6 +46,9 @@ C_TO_JULIA = {
     "const char *": {"Cstring"},
     "const nsk_ns_params *": {"Ref{Params}"},
     "const nsk_ns_state *": {"Ref{State}"},
+    "const nsk_bub_params *": {"Ref{BubParams}"},
+    "const nsk_bub_dns_state *": {"Ref{DnsState}"},
+    "nsk_bub_code3_state *": {"Ref{Code3State}"},
 }
 
 
@@ -110,7 +113,8 @@ def test_every_declared_function_has_a_stub():
 def test_structs_match_the_header():
     text = strip_comments(open(os.path.join(ROOT, "include", "nsk.h")).read())
     jl = re.sub(r"#[^\n]*", "", open(os.path.join(ROOT, "julia", "NSK.jl")).read())
-    for cname, jname in (("nsk_ns_params", "Params"), ("nsk_ns_state", "State")):
+    for cname, jname in (("nsk_ns_params", "Params"), ("nsk_ns_state", "State"), ("nsk_bub_params", "BubParams"),
+                         ("nsk_bub_dns_state", "DnsState"), ("nsk_bub_code3_state", "Code3State")):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, re.S).group(1)
         want = []
         for decl in body.split(";"):

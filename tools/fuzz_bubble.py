@@ -43,6 +43,7 @@ def sweep(cases, seed, verbose=True):
                           dt=0.00125 * (32 / max(nx, ny)) ** 2,
                           pressure_solver=str(rng.choice(["sor", "sor", "sor", "redblack", "pt"])), **common)
             g, o = DNS(q), OracleDNS(q)
+            g.fused = bool(rng.integers(0, 2))
             for _ in range(steps):
                 if g.step() != o.step():
                     ok, why = False, "sweep count"
@@ -56,6 +57,7 @@ def sweep(cases, seed, verbose=True):
                             sigma=float(rng.choice([0.0, 1.0, 10.0])), m2=float(rng.choice([0.01, 0.05])),
                             maxError=float(rng.choice([1e-3, 1e-5, 1e-1])), dt0=0.00125 * (32 / max(nx, ny)) ** 2, **common)
             g, o = Code3(q), OracleCode3(q)
+            g.fused = bool(rng.integers(0, 2))
             left = False
             for _ in range(steps):
                 try:
