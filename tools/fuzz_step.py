@@ -49,15 +49,18 @@ def sweep(cases, seed, max_n, verbose=True):
         p = p.with_(dt=p.dt * float(rng.uniform(0.2, 3.0)), **kw)
         sim, ref = NavierStokes(p), OracleSim(p)
         sim.ctx.set_option("step_fused", fused)
-        vscale = float(rng.choice([0.0, 0.1, 1.0, 5.0]))   # 5: back-traces of several cells, clamped at the walls
+        # 5: back-traces of several cells, clamped at the walls; tiny and huge scales as well
+        vscale = float(rng.choice([0.0, 0.1, 1.0, 5.0, 1e-268, 1e-290, 1e-305, 1e280]))
         for k, shape in (("Vx", (nx + 1, ny)), ("Vy", (nx, ny + 1)), ("C", (nx, ny)), ("Pr", (nx, ny))):
-            arr = np.asfortranarray(rng.standard_normal(shape) * (vscale if k != "Pr" else 1e-3))
+            arr = np.asfortranarray(rng.standard_normal(shape) * (vscale if k != "Pr" else (1e-3 * vscale if 0.0 < vscale < 0.1 else 1e-3)))
             getattr(sim, k).set(arr)
             getattr(ref, k)[...] = arr
         ok, why = True, ""
         with np.errstate(all="ignore"):
             for _ in range(2):
-                if sim.step() != ref.step() or sim.err_evo != ref.err_evo:
+                same_iters = sim.step() == ref.step() and sim.iter_evo == ref.iter_evo
+                # residuals as bit patterns: a NaN residual (which ends the loop) must compare equal
+                if not same_iters or not strict_same(np.array(sim.err_evo), np.array(ref.err_evo)):
                     ok, why = False, "iteration count / error history"
         got = sim.host_fields()
         for k in ("Pr", "Vx", "Vy", "C"):
