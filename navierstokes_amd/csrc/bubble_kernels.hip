@@ -925,6 +925,27 @@ extern "C" int nsk_bub_regrid_front(nsk_ctx *ctx, double *xf, double *yf, double
 // points queue a whole time step and wait once, at its end, for the sweep counts (and the new front
 // size): same kernels, same order, same values as the kernel-by-kernel sequence.
 namespace {
+// Up to six (a, b, n) pairs in one launch: a = b (AVERAGE false) or a = 0.5*(a + b) (code3_fun.jl:445-450).
+struct Pairs {
+  double *a[6];
+  const double *b[6];
+  size_t n[6];
+};
+template <bool AVERAGE>
+__global__ void k_pairs(Pairs P) {
+  const int q = blockIdx.y;
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < P.n[q]) P.a[q][k] = AVERAGE ? 0.5 * (P.a[q][k] + P.b[q][k]) : P.b[q][k];
+}
+template <bool AVERAGE>
+int launch_pairs(nsk_ctx *ctx, const Pairs &P, int count) {
+  size_t nmax = 0;
+  for (int q = 0; q < count; q++) nmax = P.n[q] > nmax ? P.n[q] : nmax;
+  if (nmax == 0) return 0;
+  k_pairs<AVERAGE><<<dim3((unsigned)((nmax + 255) / 256), count), 256, 0, ctx->stream>>>(P);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
 // words 8.. of the context's reduction scratch: sweep counts of the step's solves, then the front size
 inline int *step_word(nsk_ctx *ctx, int k) { return reinterpret_cast<int *>(ctx->red_dev + 8 + k); }
 inline int host_word(nsk_ctx *ctx, int k) { return *reinterpret_cast<int *>(ctx->red_host + 8 + k); }
@@ -966,12 +987,12 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
   const int nx = q->nx, ny = q->ny, Nf = s->Nf;
   NSK_BGRID_OK(nx, ny);
   NSK_REQUIRE(Nf >= 1 && s->cap >= Nf + 2, "nsk_bub_code3_step: front of %d points in vectors of %d", Nf, s->cap);
-  const size_t w = sizeof(double), nu = (size_t)(nx + 1) * (ny + 2), nv = (size_t)(nx + 2) * (ny + 1),
+  const size_t nu = (size_t)(nx + 1) * (ny + 2), nv = (size_t)(nx + 2) * (ny + 1),
                nc = (size_t)(nx + 2) * (ny + 2), nf = (size_t)Nf + 2;
-  struct { double *to; const double *from; size_t n; } keep[] = {{s->un, s->u, nu}, {s->vn, s->v, nv}, {s->rn, s->r, nc},
-                                                                 {s->mn, s->m, nc}, {s->xfn, s->xf, (size_t)s->cap},
-                                                                 {s->yfn, s->yf, (size_t)s->cap}};
-  for (auto &k : keep) NSK_HIP(hipMemcpyAsync(k.to, k.from, k.n * w, hipMemcpyDeviceToDevice, ctx->stream));
+  // un, vn, rn, mn, xfn, yfn = u, v, r, m, xf, yf (:357-362) in one launch
+  const Pairs keep{{s->un, s->vn, s->rn, s->mn, s->xfn, s->yfn}, {s->u, s->v, s->r, s->m, s->xf, s->yf},
+                   {nu, nv, nc, nc, (size_t)s->cap, (size_t)s->cap}};
+  if (int rc = launch_pairs<false>(ctx, keep, 6)) return rc;
   for (int sub = 0; sub < 2; sub++) {
     if (int rc = nsk_bub_surface_tension(ctx, s->fx, s->fy, s->tx, s->ty, s->xf, s->yf, q->sigma, q->dx, q->dy, nx, ny, Nf)) return rc;
     if (int rc = nsk_bub_set_tangential(ctx, s->u, s->v, q->usouth, q->unorth, q->vwest, q->veast, nx, ny)) return rc;
@@ -991,12 +1012,9 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
     if (int rc = nsk_bub_update_visco(ctx, s->r, s->m, q->m1, q->m2, q->rho1, q->rho2, nx, ny)) return rc;
   }
   // second-order averaging, code3_fun.jl:445-450
-  if (int rc = nsk_bub_average(ctx, s->u, s->un, nu)) return rc;
-  if (int rc = nsk_bub_average(ctx, s->v, s->vn, nv)) return rc;
-  if (int rc = nsk_bub_average(ctx, s->r, s->rn, nc)) return rc;
-  if (int rc = nsk_bub_average(ctx, s->m, s->mn, nc)) return rc;
-  if (int rc = nsk_bub_average(ctx, s->xf, s->xfn, nf)) return rc;
-  if (int rc = nsk_bub_average(ctx, s->yf, s->yfn, nf)) return rc;
+  const Pairs avg{{s->u, s->v, s->r, s->m, s->xf, s->yf}, {s->un, s->vn, s->rn, s->mn, s->xfn, s->yfn},
+                  {nu, nv, nc, nc, nf, nf}};
+  if (int rc = launch_pairs<true>(ctx, avg, 6)) return rc;
   // regridding, :455-494; the front size travels with the sweep counts
   int *d_nf = step_word(ctx, 4);
   *reinterpret_cast<int *>(ctx->red_host + 16) = Nf;
