@@ -62,6 +62,8 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *                          division; a form the two divisors dx, dy do not qualify for is replaced
  *                          by the next exact one (2 -> 3 -> 4 -> IEEE)
  *   "poisson_div_used"     (read only) the form the last fused Poisson call ran
+ *   "poisson_edge_task_rows" nsk_ns_poisson_iters_edges_first: rows per task of the edge rows' launch
+ *                          (0 = 6)
  *   "sor_pipeline"         nsk_bub_solve_pressure / nsk_bub_construct_den: 1 = several lexicographic sweeps
  *                          in flight on the anti-diagonals when the grid fits LDS (default), 0 = one
  *                          sweep at a time; same results
