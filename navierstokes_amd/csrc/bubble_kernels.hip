@@ -306,6 +306,30 @@ __global__ void __launch_bounds__(1024) k_sor(SorArgs A) {
   }
 }
 
+// Maximum of a 64-bit unsigned value over the 32-lane halves (or the whole) of a wavefront with
+// DPP row shifts and row broadcasts instead of LDS shuffles: the result is in lane 31 and lane 63
+// (halves) or in lane 63 (whole).  Lanes shifted in from outside a row contribute 0, and the
+// maximum does not mind operands that overlap.
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long m, bool whole) {
+  auto step = [&](auto ctrl, auto row_mask) {
+    constexpr int C = decltype(ctrl)::value, RM = decltype(row_mask)::value;
+    const int lo = (int)(unsigned)m, hi = (int)(unsigned)(m >> 32);
+    // disabled rows keep their own value (old = src)
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(RM == 0xf ? 0 : lo, lo, C, RM, 0xf, RM == 0xf);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(RM == 0xf ? 0 : hi, hi, C, RM, 0xf, RM == 0xf);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    m = o > m ? o : m;
+  };
+  using std::integral_constant;
+  step(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});  // row_shr:1
+  step(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});  // row_shr:2
+  step(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});  // row_shr:4
+  step(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});  // row_shr:8: lane 15 of a row = its maximum
+  step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
+  if (whole) step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2, 3
+  return m;
+}
+
 // ---- several sweeps in flight ------------------------------------------------------------
 // A lexicographic sweep is a chain of nx+ny-1 anti-diagonals, but sweep k+1 may work on diagonal e
 // as soon as sweep k has finished diagonal e+1: its cells need the values of THIS sweep to the left
@@ -322,23 +346,41 @@ __global__ void __launch_bounds__(1024) k_sor(SorArgs A) {
 // the sweeps behind it were speculation and are dropped.
 // Slot w runs sweeps w+1, w+1+W, ...: sweep (b W + w + 1) works on diagonal e at step
 // 2w + b T + e, T = max(nx+ny-1, 2W).  All counters are kept incrementally (no integer division).
-template <int MODE>
+//
+// What does not change from sweep to sweep is formed once, in LDS, by the expressions of the
+// reference: beta*tmp2 for the pressure and, when a fifth array fits (PRE), the face denominators
+// dx*(rt[i+1,j]+rt[i,j]) and dy*(rt[i,j+1]+rt[i,j]) (the sum is commutative, so the same array serves
+// the left / lower face of the next cell); dx*fx and dy*fy for the density.
+template <int MODE, bool PRE>
 __global__ void __launch_bounds__(1024) k_sor_pipe(SorArgs A, double *snap, int W, int G) {
   extern __shared__ double lds[];
   __shared__ unsigned long long slot_max[32];
   const int nx = A.nx, ny = A.ny, ld = nx + 2;
   const int tid = threadIdx.x, nth = blockDim.x;
   const int ncell = ld * (ny + 2), R = W + 1;
-  double *a = lds, *c1 = lds + ncell, *c2 = c1 + ncell, *rt = c2 + ncell;
+  const double beta = A.beta, dx = A.dx, dy = A.dy;
+  // pressure: a, tmp1, beta*tmp2, then rt or the two face arrays; density: a, dx*fx, dy*fy
+  double *a = lds, *c1 = lds + ncell, *c2 = c1 + ncell, *rt = c2 + ncell, *fy = rt + ncell;
+  double *fxd = rt;  // PRE: x-face denominators in rt's place, y-face denominators behind them
   for (int k = tid; k < ncell; k += nth) {
     a[k] = A.a[k];
-    c1[k] = A.c1[k];
-    c2[k] = A.c2[k];
-    if (MODE == 0) rt[k] = A.c3[k];
+    if (MODE == 0) {
+      c1[k] = A.c1[k];
+      c2[k] = beta * A.c2[k];
+      if (!PRE) {
+        rt[k] = A.c3[k];
+      } else {
+        const int i0 = k % ld, j0 = k / ld;  // 0-based
+        fxd[k] = i0 + 1 < ld ? dx * (A.c3[k + 1] + A.c3[k]) : 0.0;
+        fy[k] = j0 + 1 < ny + 2 ? dy * (A.c3[k + ld] + A.c3[k]) : 0.0;
+      }
+    } else {
+      c1[k] = dx * A.c1[k];
+      c2[k] = dy * A.c2[k];
+    }
   }
   if (tid < 32) slot_max[tid] = 0;
   __syncthreads();
-  const double beta = A.beta, dx = A.dx, dy = A.dy;
   const int ND = nx + ny - 1, T = ND > 2 * W ? ND : 2 * W;
   const int w = tid / G, lane = tid - w * G;  // this thread's slot and place on the diagonal
   const int red_lanes = G < 64 ? G : 64;      // lanes of one wavefront that belong to one slot
@@ -358,34 +400,31 @@ __global__ void __launch_bounds__(1024) k_sor_pipe(SorArgs A, double *snap, int 
       for (int i = 2 + lane; i <= nx + 1; i += G) {
         const int j = d - i;
         if (j < 2 || j > ny + 1) continue;
-        const double old = B2(a, ld, i, j);
+        const int q = (j - 1) * ld + (i - 1);  // this cell; q +- 1, q +- ld its neighbours
+        const double old = a[q];
         double nw;
         if (MODE == 0) {
-          nw = (1.0 - beta) * old +
-               beta * B2(c2, ld, i, j) *
-                   ((1.0 / dx) * (B2(a, ld, i + 1, j) / (dx * (RT(i + 1, j) + RT(i, j))) +
-                                  B2(a, ld, i - 1, j) / (dx * (RT(i - 1, j) + RT(i, j)))) +
-                    (1.0 / dy) * (B2(a, ld, i, j + 1) / (dy * (RT(i, j + 1) + RT(i, j))) +
-                                  B2(a, ld, i, j - 1) / (dy * (RT(i, j - 1) + RT(i, j)))) -
-                    B2(c1, ld, i, j));
+          double ex, ey;  // the two brackets of code1.m:70-73
+          if (PRE) {
+            ex = a[q + 1] / fxd[q] + a[q - 1] / fxd[q - 1];
+            ey = a[q + ld] / fy[q] + a[q - ld] / fy[q - ld];
+          } else {
+            ex = a[q + 1] / (dx * (rt[q + 1] + rt[q])) + a[q - 1] / (dx * (rt[q - 1] + rt[q]));
+            ey = a[q + ld] / (dy * (rt[q + ld] + rt[q])) + a[q - ld] / (dy * (rt[q - ld] + rt[q]));
+          }
+          nw = (1.0 - beta) * old + c2[q] * ((1.0 / dx) * ex + (1.0 / dy) * ey - c1[q]);
         } else {
           nw = (1.0 - beta) * old +
-               beta * (0.25 * (B2(a, ld, i + 1, j) + B2(a, ld, i - 1, j) + B2(a, ld, i, j + 1) +
-                               B2(a, ld, i, j - 1) + dx * B2(c1, ld, i - 1, j) - dx * B2(c1, ld, i, j) +
-                               dy * B2(c2, ld, i, j - 1) - dy * B2(c2, ld, i, j)));
+               beta * (0.25 * (a[q + 1] + a[q - 1] + a[q + ld] + a[q - ld] + c1[q - 1] - c1[q] + c2[q - ld] - c2[q]));
         }
-        B2(a, ld, i, j) = nw;
-        B2(my_snap, ld, i, j) = nw;
+        a[q] = nw;
+        my_snap[q] = nw;
         const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(old - nw));
         mymax = b > mymax ? b : mymax;
       }
       if (e == ND - 1) {  // the sweep is complete: its max|old-new| (integer max of the bit patterns keeps NaN)
-        unsigned long long m = mymax;
-        for (int off = red_lanes >> 1; off > 0; off >>= 1) {
-          const unsigned long long o = __shfl_xor(m, off, 64);
-          m = o > m ? o : m;
-        }
-        if ((lane & (red_lanes - 1)) == 0) atomicMax(&slot_max[w], m);
+        const unsigned long long m = dpp_max_u64(mymax, red_lanes == 64);
+        if ((lane & (red_lanes - 1)) == red_lanes - 1) atomicMax(&slot_max[w], m);
       }
     }
     if (++e == T) {
@@ -635,7 +674,9 @@ int launch_sor(nsk_ctx *ctx, int mode, double *a, const double *c1, const double
     const int need = (nx + ny - 1 + 1) / 2;  // more slots than this are never busy together
     if (W > need) W = need;
     if (W > maxit) W = maxit;
-    const size_t pbytes = bytes * (mode == 0 ? 4 : 3);
+    // pressure: four arrays, five when the face denominators fit as well; density: three
+    const bool pre = mode == 0 && bytes * 5 <= 156 * 1024;
+    const size_t pbytes = bytes * (mode == 0 ? (pre ? 5 : 4) : 3);
     if (ctx->sor_pipeline && W >= 2 && pbytes <= 156 * 1024) {
       const size_t snap_elems = (size_t)(W + 1) * (nx + 2) * (ny + 2);
       if (ctx->sor_snap_elems < snap_elems) {
@@ -646,13 +687,16 @@ int launch_sor(nsk_ctx *ctx, int mode, double *a, const double *c1, const double
         ctx->sor_snap_elems = snap_elems;
       }
       const int nth = (W * G + 63) / 64 * 64;  // threads past W*G own a slot >= W that never starts
-      if (mode == 0) {
-        NSK_HIP(hipFuncSetAttribute((const void *)k_sor_pipe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pbytes));
-        k_sor_pipe<0><<<1, nth, pbytes, ctx->stream>>>(A, ctx->sor_snap, W, G);
-      } else {
-        NSK_HIP(hipFuncSetAttribute((const void *)k_sor_pipe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pbytes));
-        k_sor_pipe<1><<<1, nth, pbytes, ctx->stream>>>(A, ctx->sor_snap, W, G);
-      }
+#define NSK_PIPE(M, P)                                                                                       \
+  do {                                                                                                       \
+    NSK_HIP(hipFuncSetAttribute((const void *)k_sor_pipe<M, P>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)pbytes));                                                               \
+    k_sor_pipe<M, P><<<1, nth, pbytes, ctx->stream>>>(A, ctx->sor_snap, W, G);                               \
+  } while (0)
+      if (mode != 0) NSK_PIPE(1, false);
+      else if (pre) NSK_PIPE(0, true);
+      else NSK_PIPE(0, false);
+#undef NSK_PIPE
       NSK_LAUNCH_CHECK();
       if (sweeps || change) {
         NSK_HIP(hipMemcpyAsync(ctx->red_host + 2, ctx->red_dev + 2, 16, hipMemcpyDeviceToHost, ctx->stream));
