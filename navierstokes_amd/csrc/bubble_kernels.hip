@@ -306,62 +306,47 @@ __global__ void __launch_bounds__(1024) k_sor(SorArgs A) {
   }
 }
 
-// Maximum of a 64-bit unsigned value over the 32-lane halves (or the whole) of a wavefront with
-// DPP row shifts and row broadcasts instead of LDS shuffles: the result is in lane 31 and lane 63
-// (halves) or in lane 63 (whole).  Lanes shifted in from outside a row contribute 0, and the
-// maximum does not mind operands that overlap.
-__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long m, bool whole) {
-  auto step = [&](auto ctrl, auto row_mask) {
-    constexpr int C = decltype(ctrl)::value, RM = decltype(row_mask)::value;
-    const int lo = (int)(unsigned)m, hi = (int)(unsigned)(m >> 32);
-    // disabled rows keep their own value (old = src)
-    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(RM == 0xf ? 0 : lo, lo, C, RM, 0xf, RM == 0xf);
-    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(RM == 0xf ? 0 : hi, hi, C, RM, 0xf, RM == 0xf);
-    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
-    m = o > m ? o : m;
-  };
-  using std::integral_constant;
-  step(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});  // row_shr:1
-  step(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});  // row_shr:2
-  step(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});  // row_shr:4
-  step(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});  // row_shr:8: lane 15 of a row = its maximum
-  step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
-  if (whole) step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2, 3
-  return m;
-}
-
 // ---- several sweeps in flight ------------------------------------------------------------
 // A lexicographic sweep is a chain of nx+ny-1 anti-diagonals, but sweep k+1 may work on diagonal e
 // as soon as sweep k has finished diagonal e+1: its cells need the values of THIS sweep to the left
 // and below (diagonal e-1) and the values of the PREVIOUS sweep of the cell itself, to the right
-// and above (diagonals e, e+1).  So W sweeps run through the diagonals two apart, each in its own
-// group of G threads ("slot"), all on ONE array in LDS updated in place: in a step the slots write
-// diagonals e, e-2, e-4, ... and read e-1..e+1, e-3..e-1, ..., which never meet, and every value is
-// formed from exactly the operands the serial sweep uses -- the results are identical bit for bit.
-// A new sweep starts every other step instead of every nx+ny-1.
+// and above (diagonals e, e+1).  So sweeps follow each other through the diagonals two steps apart,
+// all on ONE array in LDS updated in place: in a step they write diagonals e, e-2, e-4, ... and read
+// e-1..e+1, e-3..e-1, ..., which never meet, and every value is formed from exactly the operands
+// the serial sweep uses -- the results are identical bit for bit.
+//
+// Threads: W groups of nx threads, a thread per column.  A thread walks up its column, one row a
+// step: thread (w, ci) works on row r of sweep b W + w + 1 at step 2w + b P + ci + r, then rests
+// until P = max(ny, 2W) steps are over and starts the column again for the group's next sweep.
+// Within a sweep the columns are one step apart (the diagonal); with 2W >= ny a new sweep starts
+// every other step and no thread ever rests for long.
+//
 // The stopping test max|old-new| < maxError belongs to whole sweeps, and by the time sweep k is
 // known to have met it the sweeps behind it have already changed the array.  Every sweep therefore
-// also stores its values into a snapshot of its own in global memory (number k mod R, R = W + 1;
-// stores only, nothing waits for them), and the snapshot of the final sweep is what is copied out;
-// the sweeps behind it were speculation and are dropped.
-// Slot w runs sweeps w+1, w+1+W, ...: sweep (b W + w + 1) works on diagonal e at step
-// 2w + b T + e, T = max(nx+ny-1, 2W).  All counters are kept incrementally (no integer division).
+// also stores its values into a snapshot of its own in global memory (number k mod R; stores only,
+// nothing waits for them), and the snapshot of the final sweep is what is copied out; the sweeps
+// behind it were speculation and are dropped.  A thread adds its column's max|old-new| to the
+// sweep's word in LDS (number k mod R as well) when it reaches the top row; sweep k is complete at
+// step 2w + b P + nx+ny-2.  R = W M with M P >= nx+ny steps between sweeps k and k+R, so a
+// snapshot and a word are reused only after their sweep has been judged.
+// All counters are kept incrementally (no integer division in the loop).
 //
 // What does not change from sweep to sweep is formed once, in LDS, by the expressions of the
 // reference: beta*tmp2 for the pressure and, when a fifth array fits (PRE), the face denominators
 // dx*(rt[i+1,j]+rt[i,j]) and dy*(rt[i,j+1]+rt[i,j]) (the sum is commutative, so the same array serves
 // the left / lower face of the next cell); dx*fx and dy*fy for the density.
 template <int MODE, bool PRE>
-__global__ void __launch_bounds__(1024) k_sor_pipe(SorArgs A, double *snap, int W, int G) {
+__global__ void __launch_bounds__(1024) k_sor_pipe(SorArgs A, double *snap, int W, int P, int M) {
   extern __shared__ double lds[];
-  __shared__ unsigned long long slot_max[32];
   const int nx = A.nx, ny = A.ny, ld = nx + 2;
   const int tid = threadIdx.x, nth = blockDim.x;
-  const int ncell = ld * (ny + 2), R = W + 1;
+  const int ncell = ld * (ny + 2), R = W * M;
   const double beta = A.beta, dx = A.dx, dy = A.dy;
   // pressure: a, tmp1, beta*tmp2, then rt or the two face arrays; density: a, dx*fx, dy*fy
+  constexpr int NARR = MODE == 0 ? (PRE ? 5 : 4) : 3;
   double *a = lds, *c1 = lds + ncell, *c2 = c1 + ncell, *rt = c2 + ncell, *fy = rt + ncell;
   double *fxd = rt;  // PRE: x-face denominators in rt's place, y-face denominators behind them
+  unsigned long long *sweep_max = reinterpret_cast<unsigned long long *>(lds + (size_t)NARR * ncell);  // [R]
   for (int k = tid; k < ncell; k += nth) {
     a[k] = A.a[k];
     if (MODE == 0) {
@@ -379,66 +364,68 @@ __global__ void __launch_bounds__(1024) k_sor_pipe(SorArgs A, double *snap, int 
       c2[k] = dy * A.c2[k];
     }
   }
-  if (tid < 32) slot_max[tid] = 0;
+  for (int k = tid; k < R; k += nth) sweep_max[k] = 0;
   __syncthreads();
-  const int ND = nx + ny - 1, T = ND > 2 * W ? ND : 2 * W;
-  const int w = tid / G, lane = tid - w * G;  // this thread's slot and place on the diagonal
-  const int red_lanes = G < 64 ? G : 64;      // lanes of one wavefront that belong to one slot
-  int e = -2 * w, k = w + 1;                  // this slot's diagonal (negative: not started) and sweep
-  double *my_snap = snap + (size_t)(k % R) * ncell;
-  int c = -(ND - 1), batch = 0;               // step counter of the completion test, see below
+  const int ND = nx + ny - 1;
+  const int w = tid / nx, ci = tid - w * nx;  // this thread's group and column (0-based)
+  const bool alive = w < W;
+  int r = -(2 * w + ci);                      // this thread's row (0-based; negative: not started)
+  int k = w + 1, ks = k == R ? 0 : k;         // its sweep, and the sweep modulo R
+  int q = ld + ci + 1;                        // its cell; q +- 1, q +- ld the neighbours
+  double *my_snap = snap + (size_t)ks * ncell;
+  int c = -(ND - 1), batch = 0, bm = 0;       // step counter of the completion test, see below
   unsigned long long mymax = 0, last = 0;
   int final_sweep = A.maxit;
   // every sweep up to maxit is complete after this many steps; the loop ends earlier by itself
-  const long long step_limit = ((long long)A.maxit / W + 2) * T + 2 * W;
+  const long long step_limit = ((long long)A.maxit / W + 2) * P + 2 * W + ND;
   for (long long t = 0; t < step_limit; t++) {
-    if (w < W && e >= 0 && e < ND && k <= A.maxit) {
-      if (e == 0) mymax = 0;
-      if (e == 1 && lane == 0) slot_max[w] = 0;  // last read a full step ago, next used at e = ND-1 >= 2
-      const int d = e + 4;                       // i + j, i, j in 2..n+1
-      // lane <-> column: from one step to the next a lane moves up its column by one row
-      for (int i = 2 + lane; i <= nx + 1; i += G) {
-        const int j = d - i;
-        if (j < 2 || j > ny + 1) continue;
-        const int q = (j - 1) * ld + (i - 1);  // this cell; q +- 1, q +- ld its neighbours
-        const double old = a[q];
-        double nw;
-        if (MODE == 0) {
-          double ex, ey;  // the two brackets of code1.m:70-73
-          if (PRE) {
-            ex = a[q + 1] / fxd[q] + a[q - 1] / fxd[q - 1];
-            ey = a[q + ld] / fy[q] + a[q - ld] / fy[q - ld];
-          } else {
-            ex = a[q + 1] / (dx * (rt[q + 1] + rt[q])) + a[q - 1] / (dx * (rt[q - 1] + rt[q]));
-            ey = a[q + ld] / (dy * (rt[q + ld] + rt[q])) + a[q - ld] / (dy * (rt[q - ld] + rt[q]));
-          }
-          nw = (1.0 - beta) * old + c2[q] * ((1.0 / dx) * ex + (1.0 / dy) * ey - c1[q]);
+    if (alive && r >= 0 && r < ny && k <= A.maxit) {
+      if (r == 0) {
+        mymax = 0;
+        // the word's previous sweep was judged at least two steps ago
+        if (ci == 0) sweep_max[ks] = 0;
+      }
+      const double old = a[q];
+      double nw;
+      if (MODE == 0) {
+        double ex, ey;  // the two brackets of code1.m:70-73
+        if (PRE) {
+          ex = a[q + 1] / fxd[q] + a[q - 1] / fxd[q - 1];
+          ey = a[q + ld] / fy[q] + a[q - ld] / fy[q - ld];
         } else {
-          nw = (1.0 - beta) * old +
-               beta * (0.25 * (a[q + 1] + a[q - 1] + a[q + ld] + a[q - ld] + c1[q - 1] - c1[q] + c2[q - ld] - c2[q]));
+          ex = a[q + 1] / (dx * (rt[q + 1] + rt[q])) + a[q - 1] / (dx * (rt[q - 1] + rt[q]));
+          ey = a[q + ld] / (dy * (rt[q + ld] + rt[q])) + a[q - ld] / (dy * (rt[q - ld] + rt[q]));
         }
-        a[q] = nw;
-        my_snap[q] = nw;
-        const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(old - nw));
-        mymax = b > mymax ? b : mymax;
+        nw = (1.0 - beta) * old + c2[q] * ((1.0 / dx) * ex + (1.0 / dy) * ey - c1[q]);
+      } else {
+        nw = (1.0 - beta) * old +
+             beta * (0.25 * (a[q + 1] + a[q - 1] + a[q + ld] + a[q - ld] + c1[q - 1] - c1[q] + c2[q - ld] - c2[q]));
       }
-      if (e == ND - 1) {  // the sweep is complete: its max|old-new| (integer max of the bit patterns keeps NaN)
-        const unsigned long long m = dpp_max_u64(mymax, red_lanes == 64);
-        if ((lane & (red_lanes - 1)) == red_lanes - 1) atomicMax(&slot_max[w], m);
-      }
+      a[q] = nw;
+      my_snap[q] = nw;
+      const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(old - nw));
+      mymax = b > mymax ? b : mymax;
+      q += ld;
+      // top of the column: its max|old-new| (integer max of the bit patterns keeps NaN)
+      if (r == ny - 1) atomicMax(&sweep_max[ks], mymax);
     }
-    if (++e == T) {
-      e = 0;
+    if (++r == P) {
+      r = 0;
+      q = ld + ci + 1;
       k += W;
-      my_snap = snap + (size_t)(k % R) * ncell;
+      ks += W;
+      if (ks >= R) ks -= R;
+      my_snap = snap + (size_t)ks * ncell;
     }
     __syncthreads();  // the step's values and, if a sweep ended, its maximum are visible to everybody
-    // Slot q completes a sweep at steps 2q + ND-1 + b T: c counts steps from ND-1 modulo T, so an
-    // even c below 2W names the slot (at most one per step), `batch` its b.
+    // Group g completes a sweep at steps 2g + ND-1 + b P: c counts steps from ND-1 modulo P, so an
+    // even c below 2W names the group (at most one per step), `batch` its b, bm = b modulo M.
     if (c >= 0 && !(c & 1) && (c >> 1) < W) {
       const int kc = batch * W + (c >> 1) + 1;
       if (kc <= A.maxit) {
-        last = slot_max[c >> 1];
+        int idx = bm * W + (c >> 1) + 1;
+        if (idx == R) idx = 0;
+        last = sweep_max[idx];
         const double ch = __longlong_as_double((long long)last);
         if (ch < A.maxError || kc == A.maxit) {  // (false for NaN: keeps sweeping, as the reference does)
           final_sweep = kc;
@@ -446,16 +433,17 @@ __global__ void __launch_bounds__(1024) k_sor_pipe(SorArgs A, double *snap, int 
         }
       }
     }
-    if (++c == T) {
+    if (++c == P) {
       c = 0;
       batch++;
+      if (++bm == M) bm = 0;
     }
   }
   // interior cells of the final sweep's snapshot (ghost cells are never written by a sweep)
   const double *fin = snap + (size_t)(final_sweep % R) * ncell;
-  for (int q = tid; q < nx * ny; q += nth) {
-    const int j = q / nx, i = q - j * nx;
-    B2(A.a, ld, i + 2, j + 2) = B2(fin, ld, i + 2, j + 2);
+  for (int i = tid; i < nx * ny; i += nth) {
+    const int j = i / nx, i0 = i - j * nx;
+    B2(A.a, ld, i0 + 2, j + 2) = B2(fin, ld, i0 + 2, j + 2);
   }
   if (tid == 0) {
     if (A.sweeps_out) *A.sweeps_out = final_sweep;
@@ -666,19 +654,19 @@ int launch_sor(nsk_ctx *ctx, int mode, double *a, const double *c1, const double
   SorArgs A{a, c1, c2, c3, beta, dx, dy, maxError, nx, ny, maxit, d_sweeps, d_change};
   const size_t bytes = sizeof(double) * (size_t)(nx + 2) * (ny + 2);
   {
-    // Several sweeps in flight when the unknown and the coefficient arrays fit the 160 KB of LDS and
-    // a diagonal fits a slot: slots of 32 lanes (two per wavefront) for grids up to 32 cells across.
-    const int nmin = nx < ny ? nx : ny;
-    const int G = nmin <= 32 ? 32 : (nmin + 63) / 64 * 64;
-    int W = G <= 512 ? 1024 / G : 0;
-    const int need = (nx + ny - 1 + 1) / 2;  // more slots than this are never busy together
-    if (W > need) W = need;
+    // Several sweeps in flight when the unknown and the coefficient arrays fit the 160 KB of LDS:
+    // W groups of nx threads, each sweep P steps after the group's previous one (see k_sor_pipe).
+    int W = nx <= 512 ? 1024 / nx : 0;
+    if (W > (ny + 1) / 2) W = (ny + 1) / 2;  // a new sweep every other step already
     if (W > maxit) W = maxit;
+    const int P = ny > 2 * W ? ny : 2 * W;
+    const int M = W >= 1 ? (nx + ny + P - 1) / P : 1;  // M P >= nx+ny-1 + 1 steps before a snapshot is reused
+    const size_t R = (size_t)W * M;
     // pressure: four arrays, five when the face denominators fit as well; density: three
-    const bool pre = mode == 0 && bytes * 5 <= 156 * 1024;
-    const size_t pbytes = bytes * (mode == 0 ? (pre ? 5 : 4) : 3);
+    const bool pre = mode == 0 && bytes * 5 + R * 8 <= 156 * 1024;
+    const size_t pbytes = bytes * (mode == 0 ? (pre ? 5 : 4) : 3) + R * 8;
     if (ctx->sor_pipeline && W >= 2 && pbytes <= 156 * 1024) {
-      const size_t snap_elems = (size_t)(W + 1) * (nx + 2) * (ny + 2);
+      const size_t snap_elems = R * (nx + 2) * (ny + 2);
       if (ctx->sor_snap_elems < snap_elems) {
         if (ctx->sor_snap) NSK_HIP(hipFree(ctx->sor_snap));
         ctx->sor_snap = nullptr;
@@ -686,12 +674,12 @@ int launch_sor(nsk_ctx *ctx, int mode, double *a, const double *c1, const double
         NSK_HIP(hipMalloc(&ctx->sor_snap, snap_elems * sizeof(double)));
         ctx->sor_snap_elems = snap_elems;
       }
-      const int nth = (W * G + 63) / 64 * 64;  // threads past W*G own a slot >= W that never starts
-#define NSK_PIPE(M, P)                                                                                       \
-  do {                                                                                                       \
-    NSK_HIP(hipFuncSetAttribute((const void *)k_sor_pipe<M, P>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                (int)pbytes));                                                               \
-    k_sor_pipe<M, P><<<1, nth, pbytes, ctx->stream>>>(A, ctx->sor_snap, W, G);                               \
+      const int nth = (W * nx + 63) / 64 * 64;  // threads past W*nx belong to no group
+#define NSK_PIPE(M_, P_)                                                                                      \
+  do {                                                                                                        \
+    NSK_HIP(hipFuncSetAttribute((const void *)k_sor_pipe<M_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)pbytes));                                                                \
+    k_sor_pipe<M_, P_><<<1, nth, pbytes, ctx->stream>>>(A, ctx->sor_snap, W, P, M);                           \
   } while (0)
       if (mode != 0) NSK_PIPE(1, false);
       else if (pre) NSK_PIPE(0, true);
