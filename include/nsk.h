@@ -67,6 +67,9 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *   "sor_pipeline"         nsk_bub_solve_pressure / nsk_bub_construct_den: 1 = several lexicographic sweeps
  *                          in flight on the anti-diagonals when the grid fits LDS (default), 0 = one
  *                          sweep at a time; same results
+ *   "bub_merge_launches"   nsk_bub_dns_step / nsk_bub_code3_step on grids the sweeps-in-flight solver takes:
+ *                          1 = the element-wise kernels around a solve are phases of the solver's launch
+ *                          (default), 0 = one launch per kernel of the reference; same results
  *   "step_fused"           nsk_ns_step: 1 = three fused kernels around the Poisson loop (default; the
  *                          stress arrays txx, tyy, txy are then not written), 0 = one launch per
  *                          call site of NavierStokes.jl:79-100 */

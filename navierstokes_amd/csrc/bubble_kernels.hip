@@ -50,9 +50,8 @@ __global__ void k_set_density(dp r, dp m, double xc, double yc, cdp x, cdp y, do
 }
 
 // code1.m:33-34 / code3_fun.jl:28-35
-__global__ void k_set_tangential(dp u, dp v, double usouth, double unorth, double vwest,
+__device__ __forceinline__ void c_set_tangential(int t, dp u, dp v, double usouth, double unorth, double vwest,
                                  double veast, int nx, int ny) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x + 1;
   if (t <= nx + 1) {
     U(t, 1) = 2 * usouth - U(t, 2);
     U(t, ny + 2) = 2 * unorth - U(t, ny + 1);
@@ -61,6 +60,9 @@ __global__ void k_set_tangential(dp u, dp v, double usouth, double unorth, doubl
     V(1, t) = 2 * vwest - V(2, t);
     V(nx + 2, t) = 2 * veast - V(nx + 1, t);
   }
+}
+__global__ void k_set_tangential(dp u, dp v, double usouth, double unorth, double vwest, double veast, int nx, int ny) {
+  c_set_tangential(blockIdx.x * blockDim.x + threadIdx.x + 1, u, v, usouth, unorth, vwest, veast, nx, ny);
 }
 
 __device__ __forceinline__ double adv_u(cdp u, cdp v, double dx, double dy, int nx, int i, int j) {
@@ -75,9 +77,8 @@ __device__ __forceinline__ double adv_v(cdp u, cdp v, double dx, double dy, int 
 }
 
 // code1.m:36-52: both temporary velocities in one launch
-__global__ void k_temp_vel(dp ut, dp vt, cdp u, cdp v, cdp r, double dt, double dx, double dy,
+__device__ __forceinline__ void c_temp_vel(int i, int j, dp ut, dp vt, cdp u, cdp v, cdp r, double dt, double dx, double dy,
                            double gx, double gy, double m0, int nx, int ny) {
-  IJ;
   if (ut && i >= 2 && i <= nx && j >= 2 && j <= ny + 1)
     B2(ut, nx + 1, i, j) =
         U(i, j) + dt * (adv_u(u, v, dx, dy, nx, i, j) +
@@ -93,11 +94,14 @@ __global__ void k_temp_vel(dp ut, dp vt, cdp u, cdp v, cdp r, double dt, double 
                              (V(i, j + 1) - 2 * V(i, j) + V(i, j - 1)) / SQ(dy)) +
                         gy);
 }
+__global__ void k_temp_vel(dp ut, dp vt, cdp u, cdp v, cdp r, double dt, double dx, double dy, double gx, double gy, double m0, int nx, int ny) {
+  IJ;
+  c_temp_vel(i, j, ut, vt, u, v, r, dt, dx, dy, gx, gy, m0, nx, ny);
+}
 
 // code3_fun.jl:37-62
-__global__ void k_temp_vel_adv(dp ut, dp vt, cdp u, cdp v, cdp r, double dt, double dx, double dy,
+__device__ __forceinline__ void c_temp_vel_adv(int i, int j, dp ut, dp vt, cdp u, cdp v, cdp r, double dt, double dx, double dy,
                                cdp fx, cdp fy, double gx, double gy, double rro, int nx, int ny) {
-  IJ;
   if (ut && i >= 2 && i <= nx && j >= 2 && j <= ny + 1) {
     const double rb = 0.5 * (R(i + 1, j) + R(i, j));
     B2(ut, nx + 1, i, j) = U(i, j) + dt * (adv_u(u, v, dx, dy, nx, i, j) + B2(fx, nx + 2, i, j) / rb -
@@ -109,12 +113,15 @@ __global__ void k_temp_vel_adv(dp ut, dp vt, cdp u, cdp v, cdp r, double dt, dou
                                            (1.0 - rro / rb) * gy);
   }
 }
+__global__ void k_temp_vel_adv(dp ut, dp vt, cdp u, cdp v, cdp r, double dt, double dx, double dy, cdp fx, cdp fy, double gx, double gy, double rro, int nx, int ny) {
+  IJ;
+  c_temp_vel_adv(i, j, ut, vt, u, v, r, dt, dx, dy, fx, fy, gx, gy, rro, nx, ny);
+}
 
 // code3_fun.jl:64-90.  The two expressions differ in what the mean density divides, as written
 // in the reference: ut += dt*(T1 + (1/dy)*(X-Y)/rbar);  vt += dt*(T1 + T2)/rbar.
-__global__ void k_temp_vel_diff(dp ut, dp vt, cdp u, cdp v, cdp r, double dt, double dx, double dy,
+__device__ __forceinline__ void c_temp_vel_diff(int i, int j, dp ut, dp vt, cdp u, cdp v, cdp r, double dt, double dx, double dy,
                                 cdp m, int nx, int ny) {
-  IJ;
   if (ut && i >= 2 && i <= nx && j >= 2 && j <= ny + 1) {
     const double t1 = (1. / dx) * 2. * (M(i + 1, j) * (1. / dx) * (U(i + 1, j) - U(i, j)) -
                                         M(i, j) * (1. / dx) * (U(i, j) - U(i - 1, j)));
@@ -136,19 +143,25 @@ __global__ void k_temp_vel_diff(dp ut, dp vt, cdp u, cdp v, cdp r, double dt, do
     B2(vt, nx + 2, i, j) = B2(vt, nx + 2, i, j) + dt * (t1 + t2) / (0.5 * (R(i, j + 1) + R(i, j)));
   }
 }
+__global__ void k_temp_vel_diff(dp ut, dp vt, cdp u, cdp v, cdp r, double dt, double dx, double dy, cdp m, int nx, int ny) {
+  IJ;
+  c_temp_vel_diff(i, j, ut, vt, u, v, r, dt, dx, dy, m, nx, ny);
+}
 
 // code1.m:55-57: rt = r with lrg on the four borders
-__global__ void k_set_boundary(dp rt, cdp r, double lrg, int nx, int ny) {
-  IJ;
+__device__ __forceinline__ void c_set_boundary(int i, int j, dp rt, cdp r, double lrg, int nx, int ny) {
   if (i > nx + 2 || j > ny + 2) return;
   const bool border = i == 1 || i == nx + 2 || j == 1 || j == ny + 2;
   RT(i, j) = border ? lrg : R(i, j);
 }
+__global__ void k_set_boundary(dp rt, cdp r, double lrg, int nx, int ny) {
+  IJ;
+  c_set_boundary(i, j, rt, r, lrg, nx, ny);
+}
 
 // code1.m:59-65 / code3_fun.jl:92-102
-__global__ void k_compute_sources(dp tmp1, dp tmp2, cdp rt, cdp ut, cdp vt, double dt, double dx,
+__device__ __forceinline__ void c_compute_sources(int i, int j, dp tmp1, dp tmp2, cdp rt, cdp ut, cdp vt, double dt, double dx,
                                   double dy, int nx, int ny) {
-  IJ;
   if (i < 2 || i > nx + 1 || j < 2 || j > ny + 1) return;
   B2(tmp1, nx + 2, i, j) = (0.5 / dt) * ((B2(ut, nx + 1, i, j) - B2(ut, nx + 1, i - 1, j)) / dx +
                                          (B2(vt, nx + 2, i, j) - B2(vt, nx + 2, i, j - 1)) / dy);
@@ -156,11 +169,14 @@ __global__ void k_compute_sources(dp tmp1, dp tmp2, cdp rt, cdp ut, cdp vt, doub
       1.0 / ((1.0 / dx) * (1.0 / (dx * (RT(i + 1, j) + RT(i, j))) + 1.0 / (dx * (RT(i - 1, j) + RT(i, j)))) +
              (1.0 / dy) * (1.0 / (dy * (RT(i, j + 1) + RT(i, j))) + 1.0 / (dy * (RT(i, j - 1) + RT(i, j)))));
 }
+__global__ void k_compute_sources(dp tmp1, dp tmp2, cdp rt, cdp ut, cdp vt, double dt, double dx, double dy, int nx, int ny) {
+  IJ;
+  c_compute_sources(i, j, tmp1, tmp2, rt, ut, vt, dt, dx, dy, nx, ny);
+}
 
 // code1.m:80-86
-__global__ void k_correct_vel(dp u, dp v, cdp ut, cdp vt, cdp p, cdp r, double dt, double dx,
+__device__ __forceinline__ void c_correct_vel(int i, int j, dp u, dp v, cdp ut, cdp vt, cdp p, cdp r, double dt, double dx,
                               double dy, int nx, int ny) {
-  IJ;
   if (u && i >= 2 && i <= nx && j >= 2 && j <= ny + 1)
     U(i, j) = B2(ut, nx + 1, i, j) -
               dt * (2.0 / dx) * (B2(p, nx + 2, i + 1, j) - B2(p, nx + 2, i, j)) / (R(i + 1, j) + R(i, j));
@@ -168,11 +184,14 @@ __global__ void k_correct_vel(dp u, dp v, cdp ut, cdp vt, cdp p, cdp r, double d
     V(i, j) = B2(vt, nx + 2, i, j) -
               dt * (2.0 / dy) * (B2(p, nx + 2, i, j + 1) - B2(p, nx + 2, i, j)) / (R(i, j + 1) + R(i, j));
 }
+__global__ void k_correct_vel(dp u, dp v, cdp ut, cdp vt, cdp p, cdp r, double dt, double dx, double dy, int nx, int ny) {
+  IJ;
+  c_correct_vel(i, j, u, v, ut, vt, p, r, dt, dx, dy, nx, ny);
+}
 
 // code1.m:88-96
-__global__ void k_advect_density(dp r, cdp ro, cdp u, cdp v, double dt, double dx, double dy,
+__device__ __forceinline__ void c_advect_density(int i, int j, dp r, cdp ro, cdp u, cdp v, double dt, double dx, double dy,
                                  double m0, int nx, int ny) {
-  IJ;
   if (i < 2 || i > nx + 1 || j < 2 || j > ny + 1) return;
 #define RO(i, j) B2(ro, nx + 2, i, j)
   R(i, j) = RO(i, j) -
@@ -182,22 +201,32 @@ __global__ void k_advect_density(dp r, cdp ro, cdp u, cdp v, double dt, double d
             (m0 * dt / dy / dy) * (RO(i, j + 1) - 2.0 * RO(i, j) + RO(i, j - 1));
 #undef RO
 }
+__global__ void k_advect_density(dp r, cdp ro, cdp u, cdp v, double dt, double dx, double dy, double m0, int nx, int ny) {
+  IJ;
+  c_advect_density(i, j, r, ro, u, v, dt, dx, dy, m0, nx, ny);
+}
 
 // code1.m:100-101 / DNS.jl:214-220
-__global__ void k_velocity(dp uu, dp vv, cdp u, cdp v, int nx, int ny) {
-  IJ;
+__device__ __forceinline__ void c_velocity(int i, int j, dp uu, dp vv, cdp u, cdp v, int nx, int ny) {
   if (i > nx + 1 || j > ny + 1) return;
   B2(uu, nx + 1, i, j) = 0.5 * (U(i, j + 1) + U(i, j));
   B2(vv, nx + 1, i, j) = 0.5 * (V(i + 1, j) + V(i, j));
 }
+__global__ void k_velocity(dp uu, dp vv, cdp u, cdp v, int nx, int ny) {
+  IJ;
+  c_velocity(i, j, uu, vv, u, v, nx, ny);
+}
 
 // code3_fun.jl:440-441 + :242-249
-__global__ void k_update_visco(cdp r, dp m, double m1, double m2, double rho1, double rho2, int nx,
+__device__ __forceinline__ void c_update_visco(int i, int j, cdp r, dp m, double m1, double m2, double rho1, double rho2, int nx,
                                int ny) {
-  IJ;
   if (i > nx + 2 || j > ny + 2) return;
   const bool inner = i >= 2 && i <= nx + 1 && j >= 2 && j <= ny + 1;
   M(i, j) = inner ? m1 + (m2 - m1) * (R(i, j) - rho1) / (rho2 - rho1) : 0.0 + m1;
+}
+__global__ void k_update_visco(cdp r, dp m, double m1, double m2, double rho1, double rho2, int nx, int ny) {
+  IJ;
+  c_update_visco(i, j, r, m, m1, m2, rho1, rho2, nx, ny);
 }
 
 // code3_fun.jl:445-450: a = 0.5*(a + b)
@@ -336,7 +365,7 @@ __global__ void __launch_bounds__(1024) k_sor(SorArgs A) {
 // dx*(rt[i+1,j]+rt[i,j]) and dy*(rt[i,j+1]+rt[i,j]) (the sum is commutative, so the same array serves
 // the left / lower face of the next cell); dx*fx and dy*fy for the density.
 template <int MODE, bool PRE>
-__global__ void __launch_bounds__(1024) k_sor_pipe(SorArgs A, double *snap, int W, int P, int M) {
+__device__ __forceinline__ void sor_pipe(const SorArgs &A, double *snap, int W, int P, int M) {
   extern __shared__ double lds[];
   const int nx = A.nx, ny = A.ny, ld = nx + 2;
   const int tid = threadIdx.x, nth = blockDim.x;
@@ -450,6 +479,10 @@ __global__ void __launch_bounds__(1024) k_sor_pipe(SorArgs A, double *snap, int 
     if (A.change_out) *A.change_out = __longlong_as_double((long long)last);
   }
 }
+template <int MODE, bool PRE>
+__global__ void __launch_bounds__(1024) k_sor_pipe(SorArgs A, double *snap, int W, int P, int M) {
+  sor_pipe<MODE, PRE>(A, snap, W, P, M);
+}
 
 // ---- front kernels ----------------------------------------------------------------------
 
@@ -538,10 +571,9 @@ __global__ void __launch_bounds__(BX * BY) k_spread(dp fx, dp fy, cdp xf, cdp yf
 
 // code3_fun.jl:144-195: interpolate the velocity to the front and move it; one thread per point,
 // then thread 0 of the last block closes the periodic ghost points.
-__global__ void k_advect_move_front(dp uf, dp vf, dp xf, dp yf, cdp u, cdp v, double dx, double dy,
+__device__ __forceinline__ void c_advect_move_front(int l, dp uf, dp vf, dp xf, dp yf, cdp u, cdp v, double dx, double dy,
                                     double dt, double Lx, double Ly, int nx, int ny, int Nf,
                                     int *out_count) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x + 2;
   if (l > Nf + 1) return;
   const double xl = xf[l - 1], yl = yf[l - 1];
   // A front point outside the box is an error in the reference (BoundsError); the index clamps
@@ -570,6 +602,9 @@ __global__ void k_advect_move_front(dp uf, dp vf, dp xf, dp yf, cdp u, cdp v, do
   xf[l - 1] = xn;
   yf[l - 1] = yn;
   if (out_count && (xn < 0.0 || xn > Lx || yn < 0.0 || yn > Ly)) atomicAdd(out_count, 1);
+}
+__global__ void k_advect_move_front(dp uf, dp vf, dp xf, dp yf, cdp u, cdp v, double dx, double dy, double dt, double Lx, double Ly, int nx, int ny, int Nf, int *out_count) {
+  c_advect_move_front(blockIdx.x * blockDim.x + threadIdx.x + 2, uf, vf, xf, yf, u, v, dx, dy, dt, Lx, Ly, nx, ny, Nf, out_count);
 }
 
 __global__ void k_close_front(dp xf, dp yf, int Nf) {
@@ -643,6 +678,43 @@ __global__ void __launch_bounds__(64) k_regrid_front(dp xf, dp yf, dp xo, dp yo,
   *Nf_io = Nn;
 }
 
+// Launch plan of k_sor_pipe / sor_pipe for a grid, or ok = false when the grid does not fit.
+struct PipePlan {
+  bool ok, pre;
+  int W, P, M, nth;
+  size_t pbytes;
+};
+PipePlan pipe_plan(const nsk_ctx *ctx, int mode, int nx, int ny, int maxit) {
+  PipePlan pl{};
+  const size_t bytes = sizeof(double) * (size_t)(nx + 2) * (ny + 2);
+  // W groups of nx threads, each sweep P steps after the group's previous one (see sor_pipe)
+  int W = nx <= 512 ? 1024 / nx : 0;
+  if (W > (ny + 1) / 2) W = (ny + 1) / 2;  // a new sweep every other step already
+  if (W > maxit) W = maxit;
+  pl.W = W;
+  pl.P = ny > 2 * W ? ny : 2 * W;
+  pl.M = W >= 1 ? (nx + ny + pl.P - 1) / pl.P : 1;  // M P >= nx+ny-1 + 1 steps before a snapshot is reused
+  const size_t R = (size_t)W * pl.M;
+  // pressure: four arrays, five when the face denominators fit as well; density: three
+  pl.pre = mode == 0 && bytes * 5 + R * 8 <= 156 * 1024;
+  pl.pbytes = bytes * (mode == 0 ? (pl.pre ? 5 : 4) : 3) + R * 8;
+  pl.nth = (W * nx + 63) / 64 * 64;  // threads past W*nx belong to no group
+  pl.ok = ctx->sor_pipeline && W >= 2 && pl.pbytes <= 156 * 1024;
+  return pl;
+}
+// the snapshots of a plan's sweeps in flight
+int pipe_reserve(nsk_ctx *ctx, const PipePlan &pl, int nx, int ny) {
+  const size_t snap_elems = (size_t)pl.W * pl.M * (nx + 2) * (ny + 2);
+  if (ctx->sor_snap_elems < snap_elems) {
+    if (ctx->sor_snap) NSK_HIP(hipFree(ctx->sor_snap));
+    ctx->sor_snap = nullptr;
+    ctx->sor_snap_elems = 0;
+    NSK_HIP(hipMalloc(&ctx->sor_snap, snap_elems * sizeof(double)));
+    ctx->sor_snap_elems = snap_elems;
+  }
+  return 0;
+}
+
 // dev_sweeps: device word that receives the sweep count instead of the default slot (the fused
 // steps read all their counters back once, at the end).
 int launch_sor(nsk_ctx *ctx, int mode, double *a, const double *c1, const double *c2,
@@ -654,32 +726,16 @@ int launch_sor(nsk_ctx *ctx, int mode, double *a, const double *c1, const double
   SorArgs A{a, c1, c2, c3, beta, dx, dy, maxError, nx, ny, maxit, d_sweeps, d_change};
   const size_t bytes = sizeof(double) * (size_t)(nx + 2) * (ny + 2);
   {
-    // Several sweeps in flight when the unknown and the coefficient arrays fit the 160 KB of LDS:
-    // W groups of nx threads, each sweep P steps after the group's previous one (see k_sor_pipe).
-    int W = nx <= 512 ? 1024 / nx : 0;
-    if (W > (ny + 1) / 2) W = (ny + 1) / 2;  // a new sweep every other step already
-    if (W > maxit) W = maxit;
-    const int P = ny > 2 * W ? ny : 2 * W;
-    const int M = W >= 1 ? (nx + ny + P - 1) / P : 1;  // M P >= nx+ny-1 + 1 steps before a snapshot is reused
-    const size_t R = (size_t)W * M;
-    // pressure: four arrays, five when the face denominators fit as well; density: three
-    const bool pre = mode == 0 && bytes * 5 + R * 8 <= 156 * 1024;
-    const size_t pbytes = bytes * (mode == 0 ? (pre ? 5 : 4) : 3) + R * 8;
-    if (ctx->sor_pipeline && W >= 2 && pbytes <= 156 * 1024) {
-      const size_t snap_elems = R * (nx + 2) * (ny + 2);
-      if (ctx->sor_snap_elems < snap_elems) {
-        if (ctx->sor_snap) NSK_HIP(hipFree(ctx->sor_snap));
-        ctx->sor_snap = nullptr;
-        ctx->sor_snap_elems = 0;
-        NSK_HIP(hipMalloc(&ctx->sor_snap, snap_elems * sizeof(double)));
-        ctx->sor_snap_elems = snap_elems;
-      }
-      const int nth = (W * nx + 63) / 64 * 64;  // threads past W*nx belong to no group
+    // Several sweeps in flight when the unknown and the coefficient arrays fit the 160 KB of LDS
+    const PipePlan pl = pipe_plan(ctx, mode, nx, ny, maxit);
+    if (pl.ok) {
+      if (int rc = pipe_reserve(ctx, pl, nx, ny)) return rc;
+      const bool pre = pl.pre;
 #define NSK_PIPE(M_, P_)                                                                                      \
   do {                                                                                                        \
     NSK_HIP(hipFuncSetAttribute((const void *)k_sor_pipe<M_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)pbytes));                                                                \
-    k_sor_pipe<M_, P_><<<1, nth, pbytes, ctx->stream>>>(A, ctx->sor_snap, W, P, M);                           \
+                                (int)pl.pbytes));                                                             \
+    k_sor_pipe<M_, P_><<<1, pl.nth, pl.pbytes, ctx->stream>>>(A, ctx->sor_snap, pl.W, pl.P, pl.M);            \
   } while (0)
       if (mode != 0) NSK_PIPE(1, false);
       else if (pre) NSK_PIPE(0, true);
@@ -980,6 +1036,95 @@ int launch_pairs(nsk_ctx *ctx, const Pairs &P, int count) {
 }
 // words 8.. of the context's reduction scratch: sweep counts of the step's solves, then the front size
 inline int *step_word(nsk_ctx *ctx, int k) { return reinterpret_cast<int *>(ctx->red_dev + 8 + k); }
+
+// On grids the sweeps-in-flight solver takes (everything fits one workgroup's LDS) the element-wise
+// kernels around a solve are phases of the same launch: the workgroup walks the grid once per phase
+// with a barrier where the reference has a kernel boundary.  Same expressions per cell, same
+// order of the phases, so the same values; a time step is a few launches instead of dozens.
+template <class F>
+__device__ __forceinline__ void for_cells(int n1, int n2, F f) {
+  for (int k = threadIdx.x; k < n1 * n2; k += blockDim.x) {
+    const int j = k / n1;
+    f(k - j * n1 + 1, j + 1);
+  }
+}
+
+// DNS.jl:71-101 in one launch
+template <bool PRE>
+__global__ void __launch_bounds__(1024) k_dns_step(nsk_bub_dns_state s, nsk_bub_params q, double *snap, int W, int P, int M,
+                                                   int *sweeps_word, double *change_word) {
+  const int nx = q.nx, ny = q.ny, n1 = nx + 2, n2 = ny + 2;
+  const int nt = (nx > ny ? nx : ny) + 1;
+  for (int t = threadIdx.x + 1; t <= nt; t += blockDim.x)
+    c_set_tangential(t, s.u, s.v, q.usouth, q.unorth, q.vwest, q.veast, nx, ny);
+  for_cells(n1, n2, [&](int i, int j) { c_set_boundary(i, j, s.rt, s.r, 1000.0, nx, ny); });
+  __syncthreads();
+  for_cells(n1, n2, [&](int i, int j) { c_temp_vel(i, j, s.ut, s.vt, s.u, s.v, s.r, q.dt, q.dx, q.dy, q.gx, q.gy, q.m1, nx, ny); });
+  __syncthreads();
+  for_cells(n1, n2, [&](int i, int j) { c_compute_sources(i, j, s.tmp1, s.tmp2, s.rt, s.ut, s.vt, q.dt, q.dx, q.dy, nx, ny); });
+  __syncthreads();
+  const SorArgs A{s.p, s.tmp1, s.tmp2, s.rt, q.beta, q.dx, q.dy, q.maxError, nx, ny, q.maxit, sweeps_word, change_word};
+  sor_pipe<0, PRE>(A, snap, W, P, M);
+  __syncthreads();
+  for_cells(n1, n2, [&](int i, int j) {
+    c_correct_vel(i, j, s.u, s.v, s.ut, s.vt, s.p, s.r, q.dt, q.dx, q.dy, nx, ny);
+    B2(s.ro, n1, i, j) = B2(s.r, n1, i, j);
+  });
+  __syncthreads();
+  for_cells(n1, n2, [&](int i, int j) {
+    c_advect_density(i, j, s.r, s.ro, s.u, s.v, q.dt, q.dx, q.dy, q.m1, nx, ny);
+    c_velocity(i, j, s.uu, s.vv, s.u, s.v, nx, ny);
+  });
+}
+
+// code3_fun.jl:403-432 of a substep in one launch: boundary velocities, predictor (advection,
+// surface tension, gravity, then diffusion), pressure solve, projection, and the front moved with
+// the new velocity.  fx, fy hold the surface tension spread to the grid.
+template <bool PRE>
+__global__ void __launch_bounds__(1024) k_code3_flow(nsk_bub_code3_state s, nsk_bub_params q, double *snap, int W, int P, int M,
+                                                     int *sweeps_word, double *change_word) {
+  const int nx = q.nx, ny = q.ny, n1 = nx + 2, n2 = ny + 2, Nf = s.Nf;
+  const int nt = (nx > ny ? nx : ny) + 1;
+  for (int t = threadIdx.x + 1; t <= nt; t += blockDim.x)
+    c_set_tangential(t, s.u, s.v, q.usouth, q.unorth, q.vwest, q.veast, nx, ny);
+  for_cells(n1, n2, [&](int i, int j) { c_set_boundary(i, j, s.rt, s.r, 1000.0, nx, ny); });
+  __syncthreads();
+  for_cells(n1, n2, [&](int i, int j) {
+    c_temp_vel_adv(i, j, s.ut, s.vt, s.u, s.v, s.r, q.dt, q.dx, q.dy, s.fx, s.fy, q.gx, q.gy, q.rro, nx, ny);
+    c_temp_vel_diff(i, j, s.ut, s.vt, s.u, s.v, s.r, q.dt, q.dx, q.dy, s.m, nx, ny);  // its own cell of ut, vt only
+  });
+  __syncthreads();
+  for_cells(n1, n2, [&](int i, int j) { c_compute_sources(i, j, s.tmp1, s.tmp2, s.rt, s.ut, s.vt, q.dt, q.dx, q.dy, nx, ny); });
+  __syncthreads();
+  const SorArgs A{s.p, s.tmp1, s.tmp2, s.rt, q.beta, q.dx, q.dy, q.maxError, nx, ny, q.maxit, sweeps_word, change_word};
+  sor_pipe<0, PRE>(A, snap, W, P, M);
+  __syncthreads();
+  for_cells(n1, n2, [&](int i, int j) { c_correct_vel(i, j, s.u, s.v, s.ut, s.vt, s.p, s.r, q.dt, q.dx, q.dy, nx, ny); });
+  __syncthreads();
+  for (int l = threadIdx.x + 2; l <= Nf + 1; l += blockDim.x)
+    c_advect_move_front(l, s.uf, s.vf, s.xf, s.yf, s.u, s.v, q.dx, q.dy, q.dt, q.Lx, q.Ly, nx, ny, Nf, nullptr);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s.xf[0] = s.xf[Nf];
+    s.yf[0] = s.yf[Nf];
+    s.xf[Nf + 1] = s.xf[1];
+    s.yf[Nf + 1] = s.yf[1];
+  }
+}
+
+// code3_fun.jl:436-441 of a substep in one launch: the density from its jump at the front (fx, fy =
+// the jump spread to the grid), then the viscosity from the density.
+__global__ void __launch_bounds__(1024) k_code3_density(nsk_bub_code3_state s, nsk_bub_params q, double *snap, int W, int P, int M,
+                                                        int *sweeps_word, double *change_word) {
+  const int nx = q.nx, ny = q.ny;
+  const SorArgs A{s.r, s.fx, s.fy, nullptr, q.beta, q.dx, q.dy, q.maxError, nx, ny, q.maxit, sweeps_word, change_word};
+  sor_pipe<1, false>(A, snap, W, P, M);
+  __syncthreads();
+  for_cells(nx + 2, ny + 2, [&](int i, int j) { c_update_visco(i, j, s.r, s.m, q.m1, q.m2, q.rho1, q.rho2, nx, ny); });
+}
+
+// phases of a launch walk the grid with every thread of the workgroup: at least 256 of them
+inline int merged_threads(const PipePlan &pl) { return pl.nth > 256 ? pl.nth : 256; }
 inline int host_word(nsk_ctx *ctx, int k) { return *reinterpret_cast<int *>(ctx->red_host + 8 + k); }
 }  // namespace
 
@@ -990,6 +1135,20 @@ extern "C" int nsk_bub_dns_step(nsk_ctx *ctx, const nsk_bub_dns_state *s, const 
   NSK_NONNULL(s->u, s->v, s->p, s->ut, s->vt, s->tmp1, s->tmp2, s->r, s->ro, s->rt, s->uu, s->vv);
   const int nx = q->nx, ny = q->ny;
   NSK_BGRID_OK(nx, ny);
+  const PipePlan pl = pipe_plan(ctx, 0, nx, ny, q->maxit);
+  if (ctx->bub_merge_launches && pl.ok && pl.pre) {
+    if (int rc = pipe_reserve(ctx, pl, nx, ny)) return rc;
+    NSK_HIP(hipFuncSetAttribute((const void *)k_dns_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.pbytes));
+    k_dns_step<true><<<1, merged_threads(pl), pl.pbytes, ctx->stream>>>(*s, *q, ctx->sor_snap, pl.W, pl.P, pl.M, step_word(ctx, 0),
+                                                                        reinterpret_cast<double *>(ctx->red_dev + 3));
+    NSK_LAUNCH_CHECK();
+    if (sweeps_out) {
+      NSK_HIP(hipMemcpyAsync(ctx->red_host + 8, ctx->red_dev + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+      NSK_HIP(hipStreamSynchronize(ctx->stream));
+      *sweeps_out = host_word(ctx, 0);
+    }
+    return 0;
+  }
   if (int rc = nsk_bub_set_tangential(ctx, s->u, s->v, q->usouth, q->unorth, q->vwest, q->veast, nx, ny)) return rc;
   if (int rc = nsk_bub_temp_vel(ctx, s->ut, s->vt, s->u, s->v, s->r, q->dt, q->dx, q->dy, q->gx, q->gy, q->m1, nx, ny)) return rc;
   if (int rc = nsk_bub_set_boundary(ctx, s->rt, s->r, 1000.0, nx, ny)) return rc;
@@ -1025,8 +1184,27 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
   const Pairs keep{{s->un, s->vn, s->rn, s->mn, s->xfn, s->yfn}, {s->u, s->v, s->r, s->m, s->xf, s->yf},
                    {nu, nv, nc, nc, (size_t)s->cap, (size_t)s->cap}};
   if (int rc = launch_pairs<false>(ctx, keep, 6)) return rc;
+  const PipePlan plp = pipe_plan(ctx, 0, nx, ny, q->maxit), pld = pipe_plan(ctx, 1, nx, ny, q->maxit);
+  const bool merged = ctx->bub_merge_launches && plp.ok && plp.pre && pld.ok;
+  if (merged) {
+    if (int rc = pipe_reserve(ctx, plp, nx, ny)) return rc;
+    if (int rc = pipe_reserve(ctx, pld, nx, ny)) return rc;
+    NSK_HIP(hipFuncSetAttribute((const void *)k_code3_flow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plp.pbytes));
+    NSK_HIP(hipFuncSetAttribute((const void *)k_code3_density, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pld.pbytes));
+  }
+  double *d_change = reinterpret_cast<double *>(ctx->red_dev + 3);
   for (int sub = 0; sub < 2; sub++) {
     if (int rc = nsk_bub_surface_tension(ctx, s->fx, s->fy, s->tx, s->ty, s->xf, s->yf, q->sigma, q->dx, q->dy, nx, ny, Nf)) return rc;
+    if (merged) {
+      k_code3_flow<true><<<1, merged_threads(plp), plp.pbytes, ctx->stream>>>(*s, *q, ctx->sor_snap, plp.W, plp.P, plp.M,
+                                                                              step_word(ctx, 2 * sub), d_change);
+      NSK_LAUNCH_CHECK();
+      if (int rc = nsk_bub_distribute(ctx, s->fx, s->fy, s->xf, s->yf, q->rho1, q->rho2, q->dx, q->dy, nx, ny, Nf)) return rc;
+      k_code3_density<<<1, merged_threads(pld), pld.pbytes, ctx->stream>>>(*s, *q, ctx->sor_snap, pld.W, pld.P, pld.M,
+                                                                           step_word(ctx, 2 * sub + 1), d_change);
+      NSK_LAUNCH_CHECK();
+      continue;
+    }
     if (int rc = nsk_bub_set_tangential(ctx, s->u, s->v, q->usouth, q->unorth, q->vwest, q->veast, nx, ny)) return rc;
     if (int rc = nsk_bub_temp_vel_adv(ctx, s->ut, s->vt, s->u, s->v, s->r, q->dt, q->dx, q->dy, s->fx, s->fy, q->gx, q->gy, q->rro, nx, ny)) return rc;
     if (int rc = nsk_bub_temp_vel_diff(ctx, s->ut, s->vt, s->u, s->v, s->r, q->dt, q->dx, q->dy, s->m, nx, ny)) return rc;

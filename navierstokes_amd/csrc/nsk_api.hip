@@ -119,6 +119,10 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
     ctx->sor_pipeline = value != 0;
     return 0;
   }
+  if (!strcmp(name, "bub_merge_launches")) {
+    ctx->bub_merge_launches = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "poisson_edge_task_rows")) {
     NSK_REQUIRE(value >= 0, "poisson_edge_task_rows must be >= 0, got %d", value);
     ctx->edge_task_rows = value;
@@ -164,6 +168,10 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   }
   if (!strcmp(name, "sor_pipeline")) {
     *value = ctx->sor_pipeline;
+    return 0;
+  }
+  if (!strcmp(name, "bub_merge_launches")) {
+    *value = ctx->bub_merge_launches;
     return 0;
   }
   if (!strcmp(name, "poisson_edge_task_rows")) {

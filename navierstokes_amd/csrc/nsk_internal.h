@@ -45,6 +45,7 @@ struct nsk_ctx {
   int edge_task_rows = 0;  // task height of the edge rows in nsk_ns_poisson_iters_edges_first, 0 = default
   // nsk_ns_poisson_iters_edges_first (created on first use): fork and edge-rows-final events
   hipEvent_t ev_fork = nullptr, ev_edge = nullptr;
+  int bub_merge_launches = 1;  // bubble time steps: 1 = element-wise kernels as phases of the solver launches on grids one workgroup holds
   int sor_pipeline = 1;  // lexicographic SOR: 1 = several sweeps in flight when everything fits LDS, 0 = one at a time
   double *sor_snap = nullptr;  // per-sweep snapshots of the unknown for that kernel
   size_t sor_snap_elems = 0;

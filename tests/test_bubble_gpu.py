@@ -163,15 +163,28 @@ def test_front_kernels(gpu, bo, nx, ny, Nf):
     assert same_bits(dxf.get()[: n2 + 2, 0], xo[: n2 + 2]) and same_bits(dyf.get()[: n2 + 2, 0], yo[: n2 + 2])
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_dns_steps(fused):
-    """scripts/DNS.jl at its sizes (32 x 32, dt .00125, beta 1.2, maxit 400): 25 steps, as one C call
-    per time step (nsk_bub_dns_step) and as one call per kernel."""
+STEP_FORMS = ["merged", "step", "kernels"]
+
+
+def step_form(g, form):
+    """merged: one C call per time step, element-wise kernels as phases of the solver launches;
+    step: one C call per time step, a launch per kernel; kernels: one C call per kernel."""
+    g.fused = form != "kernels"
+    g.ctx.set_option("bub_merge_launches", int(form == "merged"))
+
+
+@pytest.mark.parametrize("form", STEP_FORMS)
+def test_dns_steps(form):
+    """scripts/DNS.jl at its sizes (32 x 32, dt .00125, beta 1.2, maxit 400): 25 steps, as one launch
+    per time step, one C call per time step (nsk_bub_dns_step) and one call per kernel."""
     q = DNSParams()
     g, o = DNS(q), OracleDNS(q)
-    g.fused = fused
-    for _ in range(25):
-        assert g.step() == o.step()
+    step_form(g, form)
+    try:
+        for _ in range(25):
+            assert g.step() == o.step()
+    finally:
+        g.ctx.set_option("bub_merge_launches", 1)
     for k in ("rho", "u", "v", "p", "uu", "vv"):
         assert same_bits(getattr(g, k).get(), getattr(o, k)), k
 
@@ -276,16 +289,21 @@ def test_dns_steps_other_solvers(solver):
         assert same_bits(getattr(g, k).get(), getattr(o, k)), k
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_code3_steps(fused):
-    """scripts/code3_fun.jl at its sizes (32 x 32, Nf = 100): 12 steps incl. front regridding, as one C
-    call per time step (nsk_bub_code3_step) and as one call per kernel."""
-    q = Code3Params()
+@pytest.mark.parametrize("form", STEP_FORMS)
+@pytest.mark.parametrize("nx,ny,Nf", [(32, 32, 100), (21, 40, 57)])
+def test_code3_steps(form, nx, ny, Nf):
+    """scripts/code3_fun.jl at its sizes (32 x 32, Nf = 100) and on an uneven grid: 12 steps incl. front
+    regridding, with the element-wise kernels merged into the solver launches, as one C call per time
+    step (nsk_bub_code3_step) and as one call per kernel."""
+    q = Code3Params(nx=nx, ny=ny, Nf=Nf)
     g, o = Code3(q), OracleCode3(q)
-    g.fused = fused
-    for _ in range(12):
-        assert g.step() == o.step()
-        assert g.Nf == o.Nf
+    step_form(g, form)
+    try:
+        for _ in range(12):
+            assert g.step() == o.step()
+            assert g.Nf == o.Nf
+    finally:
+        g.ctx.set_option("bub_merge_launches", 1)
     for k in ("r", "m", "u", "v", "p"):
         assert same_bits(getattr(g, k).get(), getattr(o, k)), k
     gx, gy = g.front()

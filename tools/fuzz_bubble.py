@@ -44,6 +44,7 @@ def sweep(cases, seed, verbose=True):
                           pressure_solver=str(rng.choice(["sor", "sor", "sor", "redblack", "pt"])), **common)
             g, o = DNS(q), OracleDNS(q)
             g.fused = bool(rng.integers(0, 2))
+            g.ctx.set_option("bub_merge_launches", int(rng.integers(0, 2)))
             for _ in range(steps):
                 if g.step() != o.step():
                     ok, why = False, "sweep count"
@@ -58,6 +59,7 @@ def sweep(cases, seed, verbose=True):
                             maxError=float(rng.choice([1e-3, 1e-5, 1e-1])), dt0=0.00125 * (32 / max(nx, ny)) ** 2, **common)
             g, o = Code3(q), OracleCode3(q)
             g.fused = bool(rng.integers(0, 2))
+            g.ctx.set_option("bub_merge_launches", int(rng.integers(0, 2)))
             left = False
             for _ in range(steps):
                 try:
