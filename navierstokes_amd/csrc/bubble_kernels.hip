@@ -506,9 +506,10 @@ __global__ void k_front_tangents(dp tx, dp ty, cdp xf, cdp yf, int Nf) {
 // Spreading as a gather (code3_fun.jl:380-401 for KIND 0, :197-222 for KIND 1): grid point
 // (i,j) of fx / fy sums, for l ascending, the weight with which front point l lands on it.
 // The cell a front point lands in, its offsets in that cell and its strength do not depend on the
-// grid point, so the workgroup works them out once per point (SPREAD_CHUNK points at a time, in
-// LDS) and every grid point then only compares cell indices, point after point in the order of
-// the reference's scatter loop.
+// grid point, so the workgroup works them out once per point (SPREAD_CHUNK points at a time) and
+// keeps, in LDS and still in ascending l, only the points that land on its tile of the grid or on
+// the ring around it; every grid point then only compares cell indices with those few, point after
+// point in the order of the reference's scatter loop.
 constexpr int SPREAD_CHUNK = BX * BY;
 template <int KIND>
 __global__ void __launch_bounds__(BX * BY) k_spread(dp fx, dp fy, cdp xf, cdp yf, cdp tx, cdp ty, double c0,
@@ -517,48 +518,77 @@ __global__ void __launch_bounds__(BX * BY) k_spread(dp fx, dp fy, cdp xf, cdp yf
   // its four (i or i-1, j or j-1)
   __shared__ unsigned long long s_key[2][SPREAD_CHUNK];
   __shared__ double s_ax[2][SPREAD_CHUNK], s_ay[2][SPREAD_CHUNK], s_nf[2][SPREAD_CHUNK];
+  __shared__ int s_cnt[2][SPREAD_CHUNK / 64];
   IJ;
-  const int tid = threadIdx.y * BX + threadIdx.x;
+  const int tid = threadIdx.y * BX + threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // points whose cell (ip, jp) has ip in [i_lo-1, i_hi] and jp in [j_lo-1, j_hi] touch this tile
+  const int i_lo = blockIdx.x * BX + 1, i_hi = i_lo + BX - 1, j_lo = blockIdx.y * BY + 1, j_hi = j_lo + BY - 1;
   auto key = [](int ip, int jp) { return (unsigned long long)(unsigned)ip | ((unsigned long long)(unsigned)jp << 32); };
   const unsigned long long k00 = key(i, j), k10 = key(i - 1, j), k01 = key(i, j - 1), k11 = key(i - 1, j - 1);
   double sx = 0.0, sy = 0.0;
   for (int l0 = 2; l0 <= Nf + 1; l0 += SPREAD_CHUNK) {
     const int l = l0 + tid;
+    int ip[2] = {0, 0}, jp[2] = {0, 0};
+    double ax[2], ay[2], nf[2];
+    bool rel[2] = {false, false};
     if (l <= Nf + 1) {
       const double xl = xf[l - 1], yl = yf[l - 1];
       if (KIND == 0) {  // surface tension, c0 = sigma
-        s_nf[0][tid] = c0 * (tx[l - 1] - tx[l - 2]);
-        s_nf[1][tid] = c0 * (ty[l - 1] - ty[l - 2]);
+        nf[0] = c0 * (tx[l - 1] - tx[l - 2]);
+        nf[1] = c0 * (ty[l - 1] - ty[l - 2]);
       } else {          // density jump, c0 = rho1, c1 = rho2
-        s_nf[0][tid] = -0.5 * (yf[l] - yf[l - 2]) * (c1 - c0);
-        s_nf[1][tid] = 0.5 * (xf[l] - xf[l - 2]) * (c1 - c0);
+        nf[0] = -0.5 * (yf[l] - yf[l - 2]) * (c1 - c0);
+        nf[1] = 0.5 * (xf[l] - xf[l - 2]) * (c1 - c0);
       }
-      {
-        const int ip = (int)floor(xl / dx) + 1, jp = (int)floor((yl + 0.5 * dy) / dy) + 1;
-        s_key[0][tid] = key(ip, jp);
-        s_ax[0][tid] = xl / dx - ip + 1;
-        s_ay[0][tid] = (yl + 0.5 * dy) / dy - jp + 1;
+      ip[0] = (int)floor(xl / dx) + 1;
+      jp[0] = (int)floor((yl + 0.5 * dy) / dy) + 1;
+      ax[0] = xl / dx - ip[0] + 1;
+      ay[0] = (yl + 0.5 * dy) / dy - jp[0] + 1;
+      ip[1] = (int)floor((xl + 0.5 * dx) / dx) + 1;
+      jp[1] = (int)floor(yl / dy) + 1;
+      ax[1] = (xl + 0.5 * dx) / dx - ip[1] + 1;
+      ay[1] = yl / dy - jp[1] + 1;
+      for (int f = 0; f < 2; f++) rel[f] = ip[f] >= i_lo - 1 && ip[f] <= i_hi && jp[f] >= j_lo - 1 && jp[f] <= j_hi;
+    }
+    // ordered compaction: place among the wavefront's points, then the wavefronts one after the other
+    int pos[2];
+    for (int f = 0; f < 2; f++) {
+      const unsigned long long mask = __ballot(rel[f]);
+      pos[f] = __popcll(mask & ((1ull << lane) - 1));
+      if (lane == 0) s_cnt[f][wave] = __popcll(mask);
+    }
+    __syncthreads();
+    int n[2];
+    for (int f = 0; f < 2; f++) {
+      int base = 0, total = 0;
+      for (int w = 0; w < SPREAD_CHUNK / 64; w++) {
+        const int cw = s_cnt[f][w];
+        base += w < wave ? cw : 0;
+        total += cw;
       }
-      {
-        const int ip = (int)floor((xl + 0.5 * dx) / dx) + 1, jp = (int)floor(yl / dy) + 1;
-        s_key[1][tid] = key(ip, jp);
-        s_ax[1][tid] = (xl + 0.5 * dx) / dx - ip + 1;
-        s_ay[1][tid] = yl / dy - jp + 1;
+      n[f] = total;
+      if (rel[f]) {
+        const int at = base + pos[f];
+        s_key[f][at] = key(ip[f], jp[f]);
+        s_ax[f][at] = ax[f];
+        s_ay[f][at] = ay[f];
+        s_nf[f][at] = nf[f];
       }
     }
     __syncthreads();
-    const int n = min(SPREAD_CHUNK, Nf + 2 - l0);
-#pragma unroll 4
-    for (int q = 0; q < n; q++) {
-      const unsigned long long kx = s_key[0][q], ky = s_key[1][q];
+    for (int q = 0; q < n[0]; q++) {
+      const unsigned long long kx = s_key[0][q];
       if (kx == k00 || kx == k10 || kx == k01 || kx == k11) {
-        const double ax = s_ax[0][q], ay = s_ay[0][q];
-        const double wx = (unsigned)kx == (unsigned)i ? 1.0 - ax : ax, wy = (unsigned)(kx >> 32) == (unsigned)j ? 1.0 - ay : ay;
+        const double axq = s_ax[0][q], ayq = s_ay[0][q];
+        const double wx = (unsigned)kx == (unsigned)i ? 1.0 - axq : axq, wy = (unsigned)(kx >> 32) == (unsigned)j ? 1.0 - ayq : ayq;
         sx = sx + wx * wy * s_nf[0][q] / dx / dy;
       }
+    }
+    for (int q = 0; q < n[1]; q++) {
+      const unsigned long long ky = s_key[1][q];
       if (ky == k00 || ky == k10 || ky == k01 || ky == k11) {
-        const double ax = s_ax[1][q], ay = s_ay[1][q];
-        const double wx = (unsigned)ky == (unsigned)i ? 1.0 - ax : ax, wy = (unsigned)(ky >> 32) == (unsigned)j ? 1.0 - ay : ay;
+        const double axq = s_ax[1][q], ayq = s_ay[1][q];
+        const double wx = (unsigned)ky == (unsigned)i ? 1.0 - axq : axq, wy = (unsigned)(ky >> 32) == (unsigned)j ? 1.0 - ayq : ayq;
         sy = sy + wx * wy * s_nf[1][q] / dx / dy;
       }
     }
@@ -621,7 +651,7 @@ __global__ void k_close_front(dp xf, dp yf, int Nf) {
 // only copy.  xo/yo: scratch copies of the old front.  *Nf_io is updated; -1 signals cap exceeded.
 __global__ void __launch_bounds__(64) k_regrid_front(dp xf, dp yf, dp xo, dp yo, double dx, double dy, int *Nf_io, int cap) {
   constexpr int LDS_POINTS = 2048;  // fronts up to this size are walked in LDS
-  __shared__ double s_x[LDS_POINTS], s_y[LDS_POINTS];
+  __shared__ double s_x[LDS_POINTS], s_y[LDS_POINTS], s_d[LDS_POINTS];
   if (blockIdx.x != 0) return;
   const int Nf = *Nf_io;
   const bool in_lds = Nf + 2 <= LDS_POINTS;
@@ -635,20 +665,29 @@ __global__ void __launch_bounds__(64) k_regrid_front(dp xf, dp yf, dp xo, dp yo,
     }
   }
   __syncthreads();
+  // Unless old point l-1 was dropped, the point written last IS old point l-1 (kept, or the far end
+  // of a split segment), so the distance the chain needs at l is the one between old neighbours:
+  // all lanes work those out, the chain computes only the ones after a dropped point.
+  if (in_lds) {
+    for (int l = 2 + threadIdx.x; l <= Nf + 1; l += 64)
+      s_d[l] = sqrt(SQ((s_x[l - 1] - s_x[l - 2]) / dx) + SQ((s_y[l - 1] - s_y[l - 2]) / dy));
+    __syncthreads();
+  }
   if (threadIdx.x != 0) return;
   if (in_lds) {
     xo = s_x;
     yo = s_y;
   }
   int j = 1;
-  bool ok = true;
+  bool ok = true, last_is_prev = in_lds;
   double lx = xo[0], ly = yo[0];  // xf[j-1], yf[j-1]: the point written last
-  double nxt_x = xo[1], nxt_y = yo[1];
+  double nxt_x = xo[1], nxt_y = yo[1], nxt_d = in_lds ? s_d[2] : 0.0;
   for (int l = 2; l <= Nf + 1 && ok; l++) {
-    const double ox = nxt_x, oy = nxt_y;  // xo[l-1], yo[l-1]
-    nxt_x = xo[l];                        // (l <= Nf+1: in range) read ahead of the chain
+    const double ox = nxt_x, oy = nxt_y, od = nxt_d;  // xo[l-1], yo[l-1], s_d[l]
+    nxt_x = xo[l];                                    // (l <= Nf+1: in range) read ahead of the chain
     nxt_y = yo[l];
-    const double ds = sqrt(SQ((ox - lx) / dx) + SQ((oy - ly) / dy));
+    if (in_lds && l + 1 < LDS_POINTS) nxt_d = s_d[l + 1];
+    const double ds = last_is_prev ? od : sqrt(SQ((ox - lx) / dx) + SQ((oy - ly) / dy));
     if (ds > 0.5) {
       j += 1;
       if (j + 2 > cap) { ok = false; break; }
@@ -657,12 +696,15 @@ __global__ void __launch_bounds__(64) k_regrid_front(dp xf, dp yf, dp xo, dp yo,
       j += 1;
       xf[j - 1] = lx = ox;
       yf[j - 1] = ly = oy;
+      last_is_prev = in_lds;
     } else if (ds < 0.25) {
+      last_is_prev = false;
     } else {
       j += 1;
       if (j + 1 > cap) { ok = false; break; }
       xf[j - 1] = lx = ox;
       yf[j - 1] = ly = oy;
+      last_is_prev = in_lds;
     }
   }
   if (!ok || j + 1 > cap) {
