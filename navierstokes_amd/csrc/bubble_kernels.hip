@@ -487,8 +487,7 @@ __global__ void __launch_bounds__(1024) k_sor_pipe(SorArgs A, double *snap, int 
 // ---- front kernels ----------------------------------------------------------------------
 
 // code3_fun.jl:372-378: tangents of segments l = 1..Nf+1 (1-based), then tx[Nf+2] = tx[2]
-__global__ void k_front_tangents(dp tx, dp ty, cdp xf, cdp yf, int Nf) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x + 1;
+__device__ __forceinline__ void c_front_tangents(int l, dp tx, dp ty, cdp xf, cdp yf, int Nf) {
   if (l <= Nf + 1) {
     const double ex = xf[l] - xf[l - 1], ey = yf[l] - yf[l - 1];
     const double ds = sqrt(SQ(ex) + SQ(ey));
@@ -501,6 +500,9 @@ __global__ void k_front_tangents(dp tx, dp ty, cdp xf, cdp yf, int Nf) {
     tx[Nf + 1] = ex / ds;
     ty[Nf + 1] = ey / ds;
   }
+}
+__global__ void k_front_tangents(dp tx, dp ty, cdp xf, cdp yf, int Nf) {
+  c_front_tangents(blockIdx.x * blockDim.x + threadIdx.x + 1, tx, ty, xf, yf, Nf);
 }
 
 // Spreading as a gather (code3_fun.jl:380-401 for KIND 0, :197-222 for KIND 1): grid point
@@ -599,6 +601,81 @@ __global__ void __launch_bounds__(BX * BY) k_spread(dp fx, dp fy, cdp xf, cdp yf
   B2(fy, nx + 2, i, j) = sy;
 }
 
+// The same spreading inside a launch of ONE workgroup (the merged time step below).  A point adds
+// to the four grid points around it (1-ax)(1-ay) nf/dx/dy, ax (1-ay) nf/dx/dy, ... -- expressions
+// that do not depend on the grid point, so the point's thread evaluates all four (per field) into
+// LDS once (`lds`: 10 arrays of `cap` values).  Then every wavefront takes tiles of 16 x 4 grid
+// points; a lane tests one point per round against the tile and its ring, and the wavefront visits
+// the points of the ballot in ascending order: a lane whose grid point is one of the four adds that
+// corner's value.
+template <int KIND>
+__device__ __forceinline__ void spread_tiles(double *lds, int cap, dp fx, dp fy, cdp xf, cdp yf, cdp tx, cdp ty, double c0,
+                                             double c1, double dx, double dy, int nx, int ny, int Nf) {
+  unsigned long long *s_key = reinterpret_cast<unsigned long long *>(lds);  // [2][cap]
+  double *s_val = lds + 2 * (size_t)cap;                                    // [2][cap][4]: corners 00, 10, 01, 11
+  auto key = [](int ip, int jp) { return (unsigned long long)(unsigned)ip | ((unsigned long long)(unsigned)jp << 32); };
+  for (int idx = threadIdx.x; idx < Nf; idx += blockDim.x) {
+    const int l = idx + 2;
+    const double xl = xf[l - 1], yl = yf[l - 1];
+    double nf[2];
+    if (KIND == 0) {  // surface tension, c0 = sigma
+      nf[0] = c0 * (tx[l - 1] - tx[l - 2]);
+      nf[1] = c0 * (ty[l - 1] - ty[l - 2]);
+    } else {          // density jump, c0 = rho1, c1 = rho2
+      nf[0] = -0.5 * (yf[l] - yf[l - 2]) * (c1 - c0);
+      nf[1] = 0.5 * (xf[l] - xf[l - 2]) * (c1 - c0);
+    }
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+      const double xs = f == 0 ? xl : xl + 0.5 * dx, ys = f == 0 ? yl + 0.5 * dy : yl;
+      const int ip = (int)floor(xs / dx) + 1, jp = (int)floor(ys / dy) + 1;
+      const double ax = xs / dx - ip + 1, ay = ys / dy - jp + 1;
+      s_key[f * cap + idx] = key(ip, jp);
+      double *v = s_val + ((size_t)f * cap + idx) * 4;
+      v[0] = (1.0 - ax) * (1.0 - ay) * nf[f] / dx / dy;
+      v[1] = ax * (1.0 - ay) * nf[f] / dx / dy;
+      v[2] = (1.0 - ax) * ay * nf[f] / dx / dy;
+      v[3] = ax * ay * nf[f] / dx / dy;
+    }
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+  const int tiles_x = (nx + 2 + 15) / 16, tiles_y = (ny + 2 + 3) / 4;
+  for (int tile = wave; tile < tiles_x * tiles_y; tile += nwaves) {
+    const int tj = tile / tiles_x, ti = tile - tj * tiles_x;
+    const int i_lo = ti * 16 + 1, j_lo = tj * 4 + 1, i = i_lo + (lane & 15), j = j_lo + (lane >> 4);
+    const unsigned long long k00 = key(i, j), k10 = key(i - 1, j), k01 = key(i, j - 1), k11 = key(i - 1, j - 1);
+    double acc[2] = {0.0, 0.0};
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+      const int o = f * cap;
+      for (int base = 0; base < Nf; base += 64) {
+        const int idx = base + lane;
+        bool rel = false;
+        if (idx < Nf) {
+          const unsigned long long kq = s_key[o + idx];
+          const int ip = (int)(unsigned)kq, jp = (int)(unsigned)(kq >> 32);
+          rel = ip >= i_lo - 1 && ip <= i_lo + 15 && jp >= j_lo - 1 && jp <= j_lo + 3;
+        }
+        unsigned long long mask = __ballot(rel);
+        while (mask) {
+          const int qd = o + base + __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const unsigned long long kq = s_key[qd];
+          const double *v = s_val + (size_t)qd * 4;
+          const double v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+          if (kq == k00 || kq == k10 || kq == k01 || kq == k11)
+            acc[f] = acc[f] + (kq == k00 ? v0 : kq == k10 ? v1 : kq == k01 ? v2 : v3);
+        }
+      }
+    }
+    if (i <= nx + 2 && j <= ny + 2) {
+      B2(fx, nx + 2, i, j) = acc[0];
+      B2(fy, nx + 2, i, j) = acc[1];
+    }
+  }
+}
+
 // code3_fun.jl:144-195: interpolate the velocity to the front and move it; one thread per point,
 // then thread 0 of the last block closes the periodic ghost points.
 __device__ __forceinline__ void c_advect_move_front(int l, dp uf, dp vf, dp xf, dp yf, cdp u, cdp v, double dx, double dy,
@@ -647,8 +724,55 @@ __global__ void k_close_front(dp xf, dp yf, int Nf) {
 }
 
 // code3_fun.jl:455-494: regridding compares every old point with the point written last, so it is
-// one chain: lane 0 walks it with the last point in registers, the other lanes of the wavefront
-// only copy.  xo/yo: scratch copies of the old front.  *Nf_io is updated; -1 signals cap exceeded.
+// one chain, walked by one lane.  Unless old point l-1 was dropped, the point written last IS old
+// point l-1 (kept, or the far end of a split segment), so the distance the chain needs at l is the
+// one between old neighbours: when `dist` is given it holds those (worked out by all lanes
+// beforehand) and the chain computes only the distances after a dropped point.
+// xo/yo: the old front; returns the new size, or -1 when `cap` points do not hold it.
+template <bool HAVE_DIST>
+__device__ __forceinline__ int regrid_chain(dp xf, dp yf, const double *xo, const double *yo, const double *dist,
+                                            double dx, double dy, int Nf, int cap) {
+  int j = 1;
+  bool last_is_prev = HAVE_DIST;
+  double lx = xo[0], ly = yo[0];  // xf[j-1], yf[j-1]: the point written last
+  double nxt_x = xo[1], nxt_y = yo[1], nxt_d = HAVE_DIST ? dist[2] : 0.0;
+  for (int l = 2; l <= Nf + 1; l++) {
+    const double ox = nxt_x, oy = nxt_y, od = nxt_d;  // xo[l-1], yo[l-1], dist[l]
+    nxt_x = xo[l];                                    // (l <= Nf+1: in range) read ahead of the chain
+    nxt_y = yo[l];
+    if (HAVE_DIST && l < Nf + 1) nxt_d = dist[l + 1];
+    const double ds = last_is_prev ? od : sqrt(SQ((ox - lx) / dx) + SQ((oy - ly) / dy));
+    if (ds > 0.5) {
+      j += 1;
+      if (j + 2 > cap) return -1;
+      xf[j - 1] = 0.5 * (ox + lx);
+      yf[j - 1] = 0.5 * (oy + ly);
+      j += 1;
+      xf[j - 1] = lx = ox;
+      yf[j - 1] = ly = oy;
+      last_is_prev = HAVE_DIST;
+    } else if (ds < 0.25) {
+      last_is_prev = false;
+    } else {
+      j += 1;
+      if (j + 1 > cap) return -1;
+      xf[j - 1] = lx = ox;
+      yf[j - 1] = ly = oy;
+      last_is_prev = HAVE_DIST;
+    }
+  }
+  if (j + 1 > cap) return -1;
+  const int Nn = j - 1;
+  xf[0] = lx;  // xf[Nn]
+  yf[0] = ly;
+  // xf[1] is the first point written (j = 2), or untouched when nothing was written
+  xf[Nn + 1] = xf[1];
+  yf[Nn + 1] = yf[1];
+  return Nn;
+}
+
+// One wavefront: the old front goes to xo/yo (scratch copies) and, when it fits, to LDS.
+// *Nf_io is updated; -1 signals cap exceeded.
 __global__ void __launch_bounds__(64) k_regrid_front(dp xf, dp yf, dp xo, dp yo, double dx, double dy, int *Nf_io, int cap) {
   constexpr int LDS_POINTS = 2048;  // fronts up to this size are walked in LDS
   __shared__ double s_x[LDS_POINTS], s_y[LDS_POINTS], s_d[LDS_POINTS];
@@ -665,59 +789,14 @@ __global__ void __launch_bounds__(64) k_regrid_front(dp xf, dp yf, dp xo, dp yo,
     }
   }
   __syncthreads();
-  // Unless old point l-1 was dropped, the point written last IS old point l-1 (kept, or the far end
-  // of a split segment), so the distance the chain needs at l is the one between old neighbours:
-  // all lanes work those out, the chain computes only the ones after a dropped point.
   if (in_lds) {
     for (int l = 2 + threadIdx.x; l <= Nf + 1; l += 64)
       s_d[l] = sqrt(SQ((s_x[l - 1] - s_x[l - 2]) / dx) + SQ((s_y[l - 1] - s_y[l - 2]) / dy));
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
-  if (in_lds) {
-    xo = s_x;
-    yo = s_y;
-  }
-  int j = 1;
-  bool ok = true, last_is_prev = in_lds;
-  double lx = xo[0], ly = yo[0];  // xf[j-1], yf[j-1]: the point written last
-  double nxt_x = xo[1], nxt_y = yo[1], nxt_d = in_lds ? s_d[2] : 0.0;
-  for (int l = 2; l <= Nf + 1 && ok; l++) {
-    const double ox = nxt_x, oy = nxt_y, od = nxt_d;  // xo[l-1], yo[l-1], s_d[l]
-    nxt_x = xo[l];                                    // (l <= Nf+1: in range) read ahead of the chain
-    nxt_y = yo[l];
-    if (in_lds && l + 1 < LDS_POINTS) nxt_d = s_d[l + 1];
-    const double ds = last_is_prev ? od : sqrt(SQ((ox - lx) / dx) + SQ((oy - ly) / dy));
-    if (ds > 0.5) {
-      j += 1;
-      if (j + 2 > cap) { ok = false; break; }
-      xf[j - 1] = 0.5 * (ox + lx);
-      yf[j - 1] = 0.5 * (oy + ly);
-      j += 1;
-      xf[j - 1] = lx = ox;
-      yf[j - 1] = ly = oy;
-      last_is_prev = in_lds;
-    } else if (ds < 0.25) {
-      last_is_prev = false;
-    } else {
-      j += 1;
-      if (j + 1 > cap) { ok = false; break; }
-      xf[j - 1] = lx = ox;
-      yf[j - 1] = ly = oy;
-      last_is_prev = in_lds;
-    }
-  }
-  if (!ok || j + 1 > cap) {
-    *Nf_io = -1;
-    return;
-  }
-  const int Nn = j - 1;
-  xf[0] = lx;  // xf[Nn]
-  yf[0] = ly;
-  // xf[1] is the first point written (j = 2), or untouched when nothing was written
-  xf[Nn + 1] = xf[1];
-  yf[Nn + 1] = yf[1];
-  *Nf_io = Nn;
+  *Nf_io = in_lds ? regrid_chain<true>(xf, yf, s_x, s_y, s_d, dx, dy, Nf, cap)
+                  : regrid_chain<false>(xf, yf, xo, yo, nullptr, dx, dy, Nf, cap);
 }
 
 // Launch plan of k_sor_pipe / sor_pipe for a grid, or ok = false when the grid does not fit.
@@ -1119,50 +1198,172 @@ __global__ void __launch_bounds__(1024) k_dns_step(nsk_bub_dns_state s, nsk_bub_
   });
 }
 
-// code3_fun.jl:403-432 of a substep in one launch: boundary velocities, predictor (advection,
-// surface tension, gravity, then diffusion), pressure solve, projection, and the front moved with
-// the new velocity.  fx, fy hold the surface tension spread to the grid.
-template <bool PRE>
-__global__ void __launch_bounds__(1024) k_code3_flow(nsk_bub_code3_state s, nsk_bub_params q, double *snap, int W, int P, int M,
-                                                     int *sweeps_word, double *change_word) {
-  const int nx = q.nx, ny = q.ny, n1 = nx + 2, n2 = ny + 2, Nf = s.Nf;
-  const int nt = (nx > ny ? nx : ny) + 1;
-  for (int t = threadIdx.x + 1; t <= nt; t += blockDim.x)
-    c_set_tangential(t, s.u, s.v, q.usouth, q.unorth, q.vwest, q.veast, nx, ny);
-  for_cells(n1, n2, [&](int i, int j) { c_set_boundary(i, j, s.rt, s.r, 1000.0, nx, ny); });
-  __syncthreads();
-  for_cells(n1, n2, [&](int i, int j) {
-    c_temp_vel_adv(i, j, s.ut, s.vt, s.u, s.v, s.r, q.dt, q.dx, q.dy, s.fx, s.fy, q.gx, q.gy, q.rro, nx, ny);
-    c_temp_vel_diff(i, j, s.ut, s.vt, s.u, s.v, s.r, q.dt, q.dx, q.dy, s.m, nx, ny);  // its own cell of ut, vt only
-  });
-  __syncthreads();
-  for_cells(n1, n2, [&](int i, int j) { c_compute_sources(i, j, s.tmp1, s.tmp2, s.rt, s.ut, s.vt, q.dt, q.dx, q.dy, nx, ny); });
-  __syncthreads();
-  const SorArgs A{s.p, s.tmp1, s.tmp2, s.rt, q.beta, q.dx, q.dy, q.maxError, nx, ny, q.maxit, sweeps_word, change_word};
-  sor_pipe<0, PRE>(A, snap, W, P, M);
-  __syncthreads();
-  for_cells(n1, n2, [&](int i, int j) { c_correct_vel(i, j, s.u, s.v, s.ut, s.vt, s.p, s.r, q.dt, q.dx, q.dy, nx, ny); });
-  __syncthreads();
-  for (int l = threadIdx.x + 2; l <= Nf + 1; l += blockDim.x)
-    c_advect_move_front(l, s.uf, s.vf, s.xf, s.yf, s.u, s.v, q.dx, q.dy, q.dt, q.Lx, q.Ly, nx, ny, Nf, nullptr);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    s.xf[0] = s.xf[Nf];
-    s.yf[0] = s.yf[Nf];
-    s.xf[Nf + 1] = s.xf[1];
-    s.yf[Nf + 1] = s.yf[1];
-  }
+// A value that is the same in every lane, moved to scalar registers (the compiler cannot know it
+// of a value read from LDS).
+template <class T>
+__device__ __forceinline__ T uniform(const T &v) {
+  static_assert(sizeof(T) % 4 == 0, "whole words");
+  union {
+    T t;
+    int w[sizeof(T) / 4];
+  } x;
+  x.t = v;
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(T) / 4; k++) x.w[k] = __builtin_amdgcn_readfirstlane(x.w[k]);
+  return x.t;
 }
 
-// code3_fun.jl:436-441 of a substep in one launch: the density from its jump at the front (fx, fy =
-// the jump spread to the grid), then the viscosity from the density.
-__global__ void __launch_bounds__(1024) k_code3_density(nsk_bub_code3_state s, nsk_bub_params q, double *snap, int W, int P, int M,
-                                                        int *sweeps_word, double *change_word) {
-  const int nx = q.nx, ny = q.ny;
-  const SorArgs A{s.r, s.fx, s.fy, nullptr, q.beta, q.dx, q.dy, q.maxError, nx, ny, q.maxit, sweeps_word, change_word};
-  sor_pipe<1, false>(A, snap, W, P, M);
+// code3_fun.jl:356-494 in one launch of one workgroup: the copies of the old state, the two
+// substeps (surface tension spread to the grid; boundary velocities, predictor, pressure solve,
+// projection, front moved with the new velocity; density jump spread to the grid, density,
+// viscosity), the second-order averaging and the regridding of the front.  words[0..3] receive the
+// sweeps of the four solves, words[4] the new front size (-1: it outgrew the vectors).
+// The argument blocks are parked in LDS and every phase reads the pointers and parameters it
+// needs from there: held in registers for the whole launch they would crowd the solvers' loops
+// out of the scalar registers.
+// Dynamic LDS: the largest of the two solvers' arrays, the front records (10 x cap values) and the
+// regridding's three vectors of Nf+2.
+template <bool PRE>
+__global__ void __launch_bounds__(1024) k_code3_step(nsk_bub_code3_state s_arg, nsk_bub_params q_arg, double *snap, int W, int P,
+                                                     int M, unsigned long long *words, double *change_word) {
+  extern __shared__ double lds[];
+  __shared__ nsk_bub_code3_state ls;
+  __shared__ nsk_bub_params lq;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  if (tid == 0) {
+    ls = s_arg;
+    lq = q_arg;
+  }
   __syncthreads();
-  for_cells(nx + 2, ny + 2, [&](int i, int j) { c_update_visco(i, j, s.r, s.m, q.m1, q.m2, q.rho1, q.rho2, nx, ny); });
+  auto word = [&](int k) { return reinterpret_cast<int *>(words + k); };  // 8-byte words, an int in each
+  {
+    // un, vn, rn, mn, xfn, yfn = u, v, r, m, xf, yf (:357-362)
+    const nsk_bub_code3_state s = uniform(ls);
+    const int nx = uniform(lq.nx), ny = uniform(lq.ny);
+    const int nu = (nx + 1) * (ny + 2), nv = (nx + 2) * (ny + 1), nc = (nx + 2) * (ny + 2);
+    for (int k = tid; k < nc; k += nth) {
+      if (k < nu) s.un[k] = s.u[k];
+      if (k < nv) s.vn[k] = s.v[k];
+      s.rn[k] = s.r[k];
+      s.mn[k] = s.m[k];
+    }
+    for (int k = tid; k < s.cap; k += nth) {
+      s.xfn[k] = s.xf[k];
+      s.yfn[k] = s.yf[k];
+    }
+  }
+  for (int sub = 0; sub < 2; sub++) {
+    __syncthreads();
+    {
+      const nsk_bub_code3_state s = uniform(ls);
+      for (int l = tid + 1; l <= s.Nf + 2; l += nth) c_front_tangents(l, s.tx, s.ty, s.xf, s.yf, s.Nf);
+    }
+    __syncthreads();
+    {
+      const nsk_bub_code3_state s = uniform(ls);
+      const nsk_bub_params q = uniform(lq);
+      spread_tiles<0>(lds, s.cap, s.fx, s.fy, s.xf, s.yf, s.tx, s.ty, q.sigma, 0.0, q.dx, q.dy, q.nx, q.ny, s.Nf);
+    }
+    __syncthreads();
+    {
+      const nsk_bub_code3_state s = uniform(ls);
+      const nsk_bub_params q = uniform(lq);
+      const int nx = q.nx, ny = q.ny, nt = (nx > ny ? nx : ny) + 1;
+      for (int t = tid + 1; t <= nt; t += nth) c_set_tangential(t, s.u, s.v, q.usouth, q.unorth, q.vwest, q.veast, nx, ny);
+      for_cells(nx + 2, ny + 2, [&](int i, int j) { c_set_boundary(i, j, s.rt, s.r, 1000.0, nx, ny); });
+    }
+    __syncthreads();
+    {
+      const nsk_bub_code3_state s = uniform(ls);
+      const nsk_bub_params q = uniform(lq);
+      const int nx = q.nx, ny = q.ny;
+      for_cells(nx + 2, ny + 2, [&](int i, int j) {
+        c_temp_vel_adv(i, j, s.ut, s.vt, s.u, s.v, s.r, q.dt, q.dx, q.dy, s.fx, s.fy, q.gx, q.gy, q.rro, nx, ny);
+        c_temp_vel_diff(i, j, s.ut, s.vt, s.u, s.v, s.r, q.dt, q.dx, q.dy, s.m, nx, ny);  // its own cell of ut, vt only
+      });
+    }
+    __syncthreads();
+    {
+      const nsk_bub_code3_state s = uniform(ls);
+      const nsk_bub_params q = uniform(lq);
+      const int nx = q.nx, ny = q.ny;
+      for_cells(nx + 2, ny + 2, [&](int i, int j) { c_compute_sources(i, j, s.tmp1, s.tmp2, s.rt, s.ut, s.vt, q.dt, q.dx, q.dy, nx, ny); });
+    }
+    __syncthreads();
+    {
+      const SorArgs A{uniform(ls.p), uniform(ls.tmp1), uniform(ls.tmp2), uniform(ls.rt), uniform(lq.beta), uniform(lq.dx), uniform(lq.dy),
+                      uniform(lq.maxError), uniform(lq.nx), uniform(lq.ny), uniform(lq.maxit), word(2 * sub), change_word};
+      sor_pipe<0, PRE>(A, snap, W, P, M);
+    }
+    __syncthreads();
+    {
+      const nsk_bub_code3_state s = uniform(ls);
+      const nsk_bub_params q = uniform(lq);
+      const int nx = q.nx, ny = q.ny;
+      for_cells(nx + 2, ny + 2, [&](int i, int j) { c_correct_vel(i, j, s.u, s.v, s.ut, s.vt, s.p, s.r, q.dt, q.dx, q.dy, nx, ny); });
+    }
+    __syncthreads();
+    {
+      const nsk_bub_code3_state s = uniform(ls);
+      const nsk_bub_params q = uniform(lq);
+      for (int l = tid + 2; l <= s.Nf + 1; l += nth)
+        c_advect_move_front(l, s.uf, s.vf, s.xf, s.yf, s.u, s.v, q.dx, q.dy, q.dt, q.Lx, q.Ly, q.nx, q.ny, s.Nf, nullptr);
+    }
+    __syncthreads();
+    {
+      const nsk_bub_code3_state s = uniform(ls);
+      const nsk_bub_params q = uniform(lq);
+      if (tid == 0) {
+        s.xf[0] = s.xf[s.Nf];
+        s.yf[0] = s.yf[s.Nf];
+        s.xf[s.Nf + 1] = s.xf[1];
+        s.yf[s.Nf + 1] = s.yf[1];
+      }
+      __syncthreads();
+      spread_tiles<1>(lds, s.cap, s.fx, s.fy, s.xf, s.yf, nullptr, nullptr, q.rho1, q.rho2, q.dx, q.dy, q.nx, q.ny, s.Nf);
+    }
+    __syncthreads();
+    {
+      const SorArgs A{uniform(ls.r), uniform(ls.fx), uniform(ls.fy), nullptr, uniform(lq.beta), uniform(lq.dx), uniform(lq.dy),
+                      uniform(lq.maxError), uniform(lq.nx), uniform(lq.ny), uniform(lq.maxit), word(2 * sub + 1), change_word};
+      sor_pipe<1, false>(A, snap, W, P, M);
+    }
+    __syncthreads();
+    {
+      const nsk_bub_code3_state s = uniform(ls);
+      const nsk_bub_params q = uniform(lq);
+      const int nx = q.nx, ny = q.ny;
+      for_cells(nx + 2, ny + 2, [&](int i, int j) { c_update_visco(i, j, s.r, s.m, q.m1, q.m2, q.rho1, q.rho2, nx, ny); });
+    }
+  }
+  __syncthreads();
+  const nsk_bub_code3_state s = uniform(ls);
+  const nsk_bub_params q = uniform(lq);
+  const int nx = q.nx, ny = q.ny, Nf = s.Nf;
+  const int nu = (nx + 1) * (ny + 2), nv = (nx + 2) * (ny + 1), nc = (nx + 2) * (ny + 2);
+  // second-order averaging, :445-450
+  for (int k = tid; k < nc; k += nth) {
+    if (k < nu) s.u[k] = 0.5 * (s.u[k] + s.un[k]);
+    if (k < nv) s.v[k] = 0.5 * (s.v[k] + s.vn[k]);
+    s.r[k] = 0.5 * (s.r[k] + s.rn[k]);
+    s.m[k] = 0.5 * (s.m[k] + s.mn[k]);
+  }
+  // ... of the front, straight into the regridding's copies of the old front (:455-494)
+  double *s_x = lds, *s_y = lds + (Nf + 2), *s_d = lds + 2 * (Nf + 2);
+  for (int k = tid; k < Nf + 2; k += nth) {
+    const double x = 0.5 * (s.xf[k] + s.xfn[k]), y = 0.5 * (s.yf[k] + s.yfn[k]);
+    s.xf[k] = x;
+    s.yf[k] = y;
+    s.xs[k] = x;
+    s.ys[k] = y;
+    s_x[k] = x;
+    s_y[k] = y;
+  }
+  __syncthreads();
+  for (int l = 2 + tid; l <= Nf + 1; l += nth)
+    s_d[l] = sqrt(SQ((s_x[l - 1] - s_x[l - 2]) / q.dx) + SQ((s_y[l - 1] - s_y[l - 2]) / q.dy));
+  __syncthreads();
+  if (tid == 0) *word(4) = regrid_chain<true>(s.xf, s.yf, s_x, s_y, s_d, q.dx, q.dy, Nf, s.cap);
 }
 
 // phases of a launch walk the grid with every thread of the workgroup: at least 256 of them
@@ -1222,31 +1423,36 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
   NSK_REQUIRE(Nf >= 1 && s->cap >= Nf + 2, "nsk_bub_code3_step: front of %d points in vectors of %d", Nf, s->cap);
   const size_t nu = (size_t)(nx + 1) * (ny + 2), nv = (size_t)(nx + 2) * (ny + 1),
                nc = (size_t)(nx + 2) * (ny + 2), nf = (size_t)Nf + 2;
+  {
+    // One launch for the whole step when one workgroup holds the solvers' arrays and the front in LDS.
+    // The two solvers share W, P, M (they depend on the grid and maxit only).
+    const PipePlan plp = pipe_plan(ctx, 0, nx, ny, q->maxit), pld = pipe_plan(ctx, 1, nx, ny, q->maxit);
+    size_t lds_bytes = plp.pbytes > pld.pbytes ? plp.pbytes : pld.pbytes;
+    const size_t front_bytes = sizeof(double) * 10 * (size_t)s->cap;  // >= the regridding's 3 (Nf+2) values
+    if (front_bytes > lds_bytes) lds_bytes = front_bytes;
+    if (ctx->bub_merge_launches && plp.ok && plp.pre && pld.ok && lds_bytes <= 156 * 1024) {
+      if (int rc = pipe_reserve(ctx, plp, nx, ny)) return rc;
+      NSK_HIP(hipFuncSetAttribute((const void *)k_code3_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      k_code3_step<true><<<1, merged_threads(plp), lds_bytes, ctx->stream>>>(*s, *q, ctx->sor_snap, plp.W, plp.P, plp.M,
+                                                                             reinterpret_cast<unsigned long long *>(step_word(ctx, 0)),
+                                                                             reinterpret_cast<double *>(ctx->red_dev + 3));
+      NSK_LAUNCH_CHECK();
+      NSK_HIP(hipMemcpyAsync(ctx->red_host + 8, ctx->red_dev + 8, 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
+      NSK_HIP(hipStreamSynchronize(ctx->stream));
+      const int nf_new = host_word(ctx, 4);
+      NSK_REQUIRE(nf_new >= 0, "nsk_bub_code3_step: the front outgrew its capacity of %d points", s->cap);
+      s->Nf = nf_new;
+      if (sweeps_out)
+        for (int k = 0; k < 4; k++) sweeps_out[k] = host_word(ctx, k);
+      return 0;
+    }
+  }
   // un, vn, rn, mn, xfn, yfn = u, v, r, m, xf, yf (:357-362) in one launch
   const Pairs keep{{s->un, s->vn, s->rn, s->mn, s->xfn, s->yfn}, {s->u, s->v, s->r, s->m, s->xf, s->yf},
                    {nu, nv, nc, nc, (size_t)s->cap, (size_t)s->cap}};
   if (int rc = launch_pairs<false>(ctx, keep, 6)) return rc;
-  const PipePlan plp = pipe_plan(ctx, 0, nx, ny, q->maxit), pld = pipe_plan(ctx, 1, nx, ny, q->maxit);
-  const bool merged = ctx->bub_merge_launches && plp.ok && plp.pre && pld.ok;
-  if (merged) {
-    if (int rc = pipe_reserve(ctx, plp, nx, ny)) return rc;
-    if (int rc = pipe_reserve(ctx, pld, nx, ny)) return rc;
-    NSK_HIP(hipFuncSetAttribute((const void *)k_code3_flow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plp.pbytes));
-    NSK_HIP(hipFuncSetAttribute((const void *)k_code3_density, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pld.pbytes));
-  }
-  double *d_change = reinterpret_cast<double *>(ctx->red_dev + 3);
   for (int sub = 0; sub < 2; sub++) {
     if (int rc = nsk_bub_surface_tension(ctx, s->fx, s->fy, s->tx, s->ty, s->xf, s->yf, q->sigma, q->dx, q->dy, nx, ny, Nf)) return rc;
-    if (merged) {
-      k_code3_flow<true><<<1, merged_threads(plp), plp.pbytes, ctx->stream>>>(*s, *q, ctx->sor_snap, plp.W, plp.P, plp.M,
-                                                                              step_word(ctx, 2 * sub), d_change);
-      NSK_LAUNCH_CHECK();
-      if (int rc = nsk_bub_distribute(ctx, s->fx, s->fy, s->xf, s->yf, q->rho1, q->rho2, q->dx, q->dy, nx, ny, Nf)) return rc;
-      k_code3_density<<<1, merged_threads(pld), pld.pbytes, ctx->stream>>>(*s, *q, ctx->sor_snap, pld.W, pld.P, pld.M,
-                                                                           step_word(ctx, 2 * sub + 1), d_change);
-      NSK_LAUNCH_CHECK();
-      continue;
-    }
     if (int rc = nsk_bub_set_tangential(ctx, s->u, s->v, q->usouth, q->unorth, q->vwest, q->veast, nx, ny)) return rc;
     if (int rc = nsk_bub_temp_vel_adv(ctx, s->ut, s->vt, s->u, s->v, s->r, q->dt, q->dx, q->dy, s->fx, s->fy, q->gx, q->gy, q->rro, nx, ny)) return rc;
     if (int rc = nsk_bub_temp_vel_diff(ctx, s->ut, s->vt, s->u, s->v, s->r, q->dt, q->dx, q->dy, s->m, nx, ny)) return rc;
