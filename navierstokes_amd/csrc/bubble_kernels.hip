@@ -1366,8 +1366,13 @@ __global__ void __launch_bounds__(1024) k_code3_step(nsk_bub_code3_state s_arg, 
   if (tid == 0) *word(4) = regrid_chain<true>(s.xf, s.yf, s_x, s_y, s_d, q.dx, q.dy, Nf, s.cap);
 }
 
-// phases of a launch walk the grid with every thread of the workgroup: at least 256 of them
-inline int merged_threads(const PipePlan &pl) { return pl.nth > 256 ? pl.nth : 256; }
+// phases of a launch walk the grid with every thread of the workgroup: as many as there are cells,
+// up to the 1024 a workgroup may have (wavefronts past the solver's only wait at its barriers)
+inline int merged_threads(const PipePlan &pl, int nx, int ny) {
+  int n = ((nx + 2) * (ny + 2) + 63) / 64 * 64;
+  if (n > 1024) n = 1024;
+  return pl.nth > n ? pl.nth : n;
+}
 inline int host_word(nsk_ctx *ctx, int k) { return *reinterpret_cast<int *>(ctx->red_host + 8 + k); }
 }  // namespace
 
@@ -1382,7 +1387,7 @@ extern "C" int nsk_bub_dns_step(nsk_ctx *ctx, const nsk_bub_dns_state *s, const 
   if (ctx->bub_merge_launches && pl.ok && pl.pre) {
     if (int rc = pipe_reserve(ctx, pl, nx, ny)) return rc;
     NSK_HIP(hipFuncSetAttribute((const void *)k_dns_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.pbytes));
-    k_dns_step<true><<<1, merged_threads(pl), pl.pbytes, ctx->stream>>>(*s, *q, ctx->sor_snap, pl.W, pl.P, pl.M, step_word(ctx, 0),
+    k_dns_step<true><<<1, merged_threads(pl, nx, ny), pl.pbytes, ctx->stream>>>(*s, *q, ctx->sor_snap, pl.W, pl.P, pl.M, step_word(ctx, 0),
                                                                         reinterpret_cast<double *>(ctx->red_dev + 3));
     NSK_LAUNCH_CHECK();
     if (sweeps_out) {
@@ -1433,7 +1438,7 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
     if (ctx->bub_merge_launches && plp.ok && plp.pre && pld.ok && lds_bytes <= 156 * 1024) {
       if (int rc = pipe_reserve(ctx, plp, nx, ny)) return rc;
       NSK_HIP(hipFuncSetAttribute((const void *)k_code3_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      k_code3_step<true><<<1, merged_threads(plp), lds_bytes, ctx->stream>>>(*s, *q, ctx->sor_snap, plp.W, plp.P, plp.M,
+      k_code3_step<true><<<1, merged_threads(plp, nx, ny), lds_bytes, ctx->stream>>>(*s, *q, ctx->sor_snap, plp.W, plp.P, plp.M,
                                                                              reinterpret_cast<unsigned long long *>(step_word(ctx, 0)),
                                                                              reinterpret_cast<double *>(ctx->red_dev + 3));
       NSK_LAUNCH_CHECK();
