@@ -67,6 +67,10 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *   "sor_pipeline"         nsk_bub_solve_pressure / nsk_bub_construct_den: 1 = several lexicographic sweeps
  *                          in flight on the anti-diagonals when the grid fits LDS (default), 0 = one
  *                          sweep at a time; same results
+ *   "sor_fast_division"    the sweeps-in-flight pressure solve: 1 = quotients by the face coefficients through
+ *                          their reciprocals and two fused corrections, which gives the bits of the IEEE
+ *                          division while operands stay in [2^-900, 2^900] (else the solve is repeated
+ *                          with IEEE divisions) (default), 0 = IEEE divisions; same results
  *   "bub_merge_launches"   nsk_bub_dns_step / nsk_bub_code3_step on grids the sweeps-in-flight solver takes:
  *                          1 = the element-wise kernels around a solve are phases of the solver's launch
  *                          (default), 0 = one launch per kernel of the reference; same results

@@ -364,20 +364,56 @@ __global__ void __launch_bounds__(1024) k_sor(SorArgs A) {
 // reference: beta*tmp2 for the pressure and, when a fifth array fits (PRE), the face denominators
 // dx*(rt[i+1,j]+rt[i,j]) and dy*(rt[i,j+1]+rt[i,j]) (the sum is commutative, so the same array serves
 // the left / lower face of the next cell); dx*fx and dy*fy for the density.
-template <int MODE, bool PRE>
+//
+// FAST (two more arrays): the four divisions of a cell by face denominators are replaced by five
+// fused operations each with the denominator's correctly rounded reciprocal r = RN(1/d), formed
+// once per face:  q0 = RN(x r), then twice q <- RN(q - RN(q d - x) r).  The first correction makes
+// q a faithful rounding of x/d whatever q0's error, the second is then Markstein's correction, which
+// returns the correctly rounded quotient -- the bits of x/d, signed zeros included
+// (tools/micro/fma_division_check.c compares 4 10^8 cases on the CPU).  It holds while no
+// intermediate leaves the normal range: denominators in [2^-100, 2^100], dividends zero or in
+// [2^-900, 2^900].  Every thread checks the denominators it forms and every value it loads or
+// produces; if one falls outside, the whole solve is run again from its inputs with IEEE divisions.
+__device__ __forceinline__ bool fast_dividend_ok(double x) {
+  const unsigned e = ((unsigned)(__double_as_longlong(x) >> 32) >> 20) & 0x7ffu;  // biased exponent
+  return e - 123u <= 1800u || x == 0.0;
+}
+__device__ __forceinline__ bool fast_divisor_ok(double d) {
+  const int hi = (int)(__double_as_longlong(d) >> 32);
+  return (unsigned)((hi >> 20) - 923) <= 200u;  // positive, 2^-100 <= d < 2^101
+}
+__device__ __forceinline__ double fast_div(double x, double d, double r) {
+  const double q0 = x * r;
+  const double t0 = __builtin_fma(q0, d, -x);
+  const double q1 = __builtin_fma(-t0, r, q0);
+  const double t1 = __builtin_fma(q1, d, -x);
+  return __builtin_fma(-t1, r, q1);
+}
+
+template <int MODE, bool PRE, bool FAST = false>
 __device__ __forceinline__ void sor_pipe(const SorArgs &A, double *snap, int W, int P, int M) {
+  static_assert(!FAST || (MODE == 0 && PRE), "the fast division belongs to the pressure solve with face arrays");
   extern __shared__ double lds[];
   const int nx = A.nx, ny = A.ny, ld = nx + 2;
   const int tid = threadIdx.x, nth = blockDim.x;
   const int ncell = ld * (ny + 2), R = W * M;
   const double beta = A.beta, dx = A.dx, dy = A.dy;
-  // pressure: a, tmp1, beta*tmp2, then rt or the two face arrays; density: a, dx*fx, dy*fy
-  constexpr int NARR = MODE == 0 ? (PRE ? 5 : 4) : 3;
+  // pressure: a, tmp1, beta*tmp2, then rt or the two face arrays (and their reciprocals); density: a, dx*fx, dy*fy
+  constexpr int NARR = MODE == 0 ? (FAST ? 7 : PRE ? 5 : 4) : 3;
   double *a = lds, *c1 = lds + ncell, *c2 = c1 + ncell, *rt = c2 + ncell, *fy = rt + ncell;
   double *fxd = rt;  // PRE: x-face denominators in rt's place, y-face denominators behind them
+  double *rfx = fy + ncell, *rfy = rfx + ncell;  // FAST
   unsigned long long *sweep_max = reinterpret_cast<unsigned long long *>(lds + (size_t)NARR * ncell);  // [R]
+  int *unsafe = reinterpret_cast<int *>(sweep_max + R);  // FAST: somebody met an operand the fast division does not cover
+  bool fast = FAST;
+  int final_sweep;
+  unsigned long long last;
+  for (;;) {  // a second round only after the fast division has met such an operand
+  bool bad = false;
   for (int k = tid; k < ncell; k += nth) {
-    a[k] = A.a[k];
+    const double ak = A.a[k];
+    a[k] = ak;
+    if (FAST) bad |= !fast_dividend_ok(ak);
     if (MODE == 0) {
       c1[k] = A.c1[k];
       c2[k] = beta * A.c2[k];
@@ -385,8 +421,17 @@ __device__ __forceinline__ void sor_pipe(const SorArgs &A, double *snap, int W, 
         rt[k] = A.c3[k];
       } else {
         const int i0 = k % ld, j0 = k / ld;  // 0-based
-        fxd[k] = i0 + 1 < ld ? dx * (A.c3[k + 1] + A.c3[k]) : 0.0;
-        fy[k] = j0 + 1 < ny + 2 ? dy * (A.c3[k + ld] + A.c3[k]) : 0.0;
+        const double dxf = i0 + 1 < ld ? dx * (A.c3[k + 1] + A.c3[k]) : 0.0;
+        const double dyf = j0 + 1 < ny + 2 ? dy * (A.c3[k + ld] + A.c3[k]) : 0.0;
+        fxd[k] = dxf;
+        fy[k] = dyf;
+        if (FAST) {
+          rfx[k] = 1.0 / dxf;
+          rfy[k] = 1.0 / dyf;
+          // the faces of interior cells are the ones that divide
+          if (i0 <= nx && j0 >= 1 && j0 <= ny) bad |= !fast_divisor_ok(dxf);
+          if (j0 <= ny && i0 >= 1 && i0 <= nx) bad |= !fast_divisor_ok(dyf);
+        }
       }
     } else {
       c1[k] = dx * A.c1[k];
@@ -394,6 +439,7 @@ __device__ __forceinline__ void sor_pipe(const SorArgs &A, double *snap, int W, 
     }
   }
   for (int k = tid; k < R; k += nth) sweep_max[k] = 0;
+  if (FAST && tid == 0) *unsafe = 0;
   __syncthreads();
   const int ND = nx + ny - 1;
   const int w = tid / nx, ci = tid - w * nx;  // this thread's group and column (0-based)
@@ -403,8 +449,9 @@ __device__ __forceinline__ void sor_pipe(const SorArgs &A, double *snap, int W, 
   int q = ld + ci + 1;                        // its cell; q +- 1, q +- ld the neighbours
   double *my_snap = snap + (size_t)ks * ncell;
   int c = -(ND - 1), batch = 0, bm = 0;       // step counter of the completion test, see below
-  unsigned long long mymax = 0, last = 0;
-  int final_sweep = A.maxit;
+  unsigned long long mymax = 0;
+  last = 0;
+  final_sweep = A.maxit;
   // every sweep up to maxit is complete after this many steps; the loop ends earlier by itself
   const long long step_limit = ((long long)A.maxit / W + 2) * P + 2 * W + ND;
   for (long long t = 0; t < step_limit; t++) {
@@ -418,7 +465,10 @@ __device__ __forceinline__ void sor_pipe(const SorArgs &A, double *snap, int W, 
       double nw;
       if (MODE == 0) {
         double ex, ey;  // the two brackets of code1.m:70-73
-        if (PRE) {
+        if (FAST && fast) {
+          ex = fast_div(a[q + 1], fxd[q], rfx[q]) + fast_div(a[q - 1], fxd[q - 1], rfx[q - 1]);
+          ey = fast_div(a[q + ld], fy[q], rfy[q]) + fast_div(a[q - ld], fy[q - ld], rfy[q - ld]);
+        } else if (PRE) {
           ex = a[q + 1] / fxd[q] + a[q - 1] / fxd[q - 1];
           ey = a[q + ld] / fy[q] + a[q - ld] / fy[q - ld];
         } else {
@@ -432,6 +482,7 @@ __device__ __forceinline__ void sor_pipe(const SorArgs &A, double *snap, int W, 
       }
       a[q] = nw;
       my_snap[q] = nw;
+      if (FAST) bad |= !fast_dividend_ok(nw);
       const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(old - nw));
       mymax = b > mymax ? b : mymax;
       q += ld;
@@ -468,6 +519,14 @@ __device__ __forceinline__ void sor_pipe(const SorArgs &A, double *snap, int W, 
       if (++bm == M) bm = 0;
     }
   }
+  if (!FAST || !fast) break;
+  if (bad) *unsafe = 1;
+  __syncthreads();
+  const bool again = *unsafe != 0;
+  __syncthreads();  // everybody has read the flag before the next round clears it
+  if (!again) break;
+  fast = false;
+  }
   // interior cells of the final sweep's snapshot (ghost cells are never written by a sweep)
   const double *fin = snap + (size_t)(final_sweep % R) * ncell;
   for (int i = tid; i < nx * ny; i += nth) {
@@ -479,9 +538,9 @@ __device__ __forceinline__ void sor_pipe(const SorArgs &A, double *snap, int W, 
     if (A.change_out) *A.change_out = __longlong_as_double((long long)last);
   }
 }
-template <int MODE, bool PRE>
+template <int MODE, bool PRE, bool FAST>
 __global__ void __launch_bounds__(1024) k_sor_pipe(SorArgs A, double *snap, int W, int P, int M) {
-  sor_pipe<MODE, PRE>(A, snap, W, P, M);
+  sor_pipe<MODE, PRE, FAST>(A, snap, W, P, M);
 }
 
 // ---- front kernels ----------------------------------------------------------------------
@@ -801,7 +860,7 @@ __global__ void __launch_bounds__(64) k_regrid_front(dp xf, dp yf, dp xo, dp yo,
 
 // Launch plan of k_sor_pipe / sor_pipe for a grid, or ok = false when the grid does not fit.
 struct PipePlan {
-  bool ok, pre;
+  bool ok, pre, fast;
   int W, P, M, nth;
   size_t pbytes;
 };
@@ -817,8 +876,11 @@ PipePlan pipe_plan(const nsk_ctx *ctx, int mode, int nx, int ny, int maxit) {
   pl.M = W >= 1 ? (nx + ny + pl.P - 1) / pl.P : 1;  // M P >= nx+ny-1 + 1 steps before a snapshot is reused
   const size_t R = (size_t)W * pl.M;
   // pressure: four arrays, five when the face denominators fit as well; density: three
-  pl.pre = mode == 0 && bytes * 5 + R * 8 <= 156 * 1024;
-  pl.pbytes = bytes * (mode == 0 ? (pl.pre ? 5 : 4) : 3) + R * 8;
+  // ... seven with the reciprocals of the fast division
+  const size_t words = R * 8 + 8;  // the sweeps' maxima and the fast division's flag
+  pl.pre = mode == 0 && bytes * 5 + words <= 156 * 1024;
+  pl.fast = mode == 0 && ctx->sor_fast_division && bytes * 7 + words <= 156 * 1024;
+  pl.pbytes = bytes * (mode == 0 ? (pl.fast ? 7 : pl.pre ? 5 : 4) : 3) + words;
   pl.nth = (W * nx + 63) / 64 * 64;  // threads past W*nx belong to no group
   pl.ok = ctx->sor_pipeline && W >= 2 && pl.pbytes <= 156 * 1024;
   return pl;
@@ -852,15 +914,16 @@ int launch_sor(nsk_ctx *ctx, int mode, double *a, const double *c1, const double
     if (pl.ok) {
       if (int rc = pipe_reserve(ctx, pl, nx, ny)) return rc;
       const bool pre = pl.pre;
-#define NSK_PIPE(M_, P_)                                                                                      \
-  do {                                                                                                        \
-    NSK_HIP(hipFuncSetAttribute((const void *)k_sor_pipe<M_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)pl.pbytes));                                                             \
-    k_sor_pipe<M_, P_><<<1, pl.nth, pl.pbytes, ctx->stream>>>(A, ctx->sor_snap, pl.W, pl.P, pl.M);            \
+#define NSK_PIPE(M_, P_, F_)                                                                                      \
+  do {                                                                                                            \
+    NSK_HIP(hipFuncSetAttribute((const void *)k_sor_pipe<M_, P_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)pl.pbytes));                                                                 \
+    k_sor_pipe<M_, P_, F_><<<1, pl.nth, pl.pbytes, ctx->stream>>>(A, ctx->sor_snap, pl.W, pl.P, pl.M);            \
   } while (0)
-      if (mode != 0) NSK_PIPE(1, false);
-      else if (pre) NSK_PIPE(0, true);
-      else NSK_PIPE(0, false);
+      if (mode != 0) NSK_PIPE(1, false, false);
+      else if (pl.fast) NSK_PIPE(0, true, true);
+      else if (pre) NSK_PIPE(0, true, false);
+      else NSK_PIPE(0, false, false);
 #undef NSK_PIPE
       NSK_LAUNCH_CHECK();
       if (sweeps || change) {
@@ -1171,7 +1234,7 @@ __device__ __forceinline__ void for_cells(int n1, int n2, F f) {
 }
 
 // DNS.jl:71-101 in one launch
-template <bool PRE>
+template <bool FAST>
 __global__ void __launch_bounds__(1024) k_dns_step(nsk_bub_dns_state s, nsk_bub_params q, double *snap, int W, int P, int M,
                                                    int *sweeps_word, double *change_word) {
   const int nx = q.nx, ny = q.ny, n1 = nx + 2, n2 = ny + 2;
@@ -1185,7 +1248,7 @@ __global__ void __launch_bounds__(1024) k_dns_step(nsk_bub_dns_state s, nsk_bub_
   for_cells(n1, n2, [&](int i, int j) { c_compute_sources(i, j, s.tmp1, s.tmp2, s.rt, s.ut, s.vt, q.dt, q.dx, q.dy, nx, ny); });
   __syncthreads();
   const SorArgs A{s.p, s.tmp1, s.tmp2, s.rt, q.beta, q.dx, q.dy, q.maxError, nx, ny, q.maxit, sweeps_word, change_word};
-  sor_pipe<0, PRE>(A, snap, W, P, M);
+  sor_pipe<0, true, FAST>(A, snap, W, P, M);
   __syncthreads();
   for_cells(n1, n2, [&](int i, int j) {
     c_correct_vel(i, j, s.u, s.v, s.ut, s.vt, s.p, s.r, q.dt, q.dx, q.dy, nx, ny);
@@ -1223,7 +1286,7 @@ __device__ __forceinline__ T uniform(const T &v) {
 // out of the scalar registers.
 // Dynamic LDS: the largest of the two solvers' arrays, the front records (10 x cap values) and the
 // regridding's three vectors of Nf+2.
-template <bool PRE>
+template <bool FAST>
 __global__ void __launch_bounds__(1024) k_code3_step(nsk_bub_code3_state s_arg, nsk_bub_params q_arg, double *snap, int W, int P,
                                                      int M, unsigned long long *words, double *change_word) {
   extern __shared__ double lds[];
@@ -1293,7 +1356,7 @@ __global__ void __launch_bounds__(1024) k_code3_step(nsk_bub_code3_state s_arg, 
     {
       const SorArgs A{uniform(ls.p), uniform(ls.tmp1), uniform(ls.tmp2), uniform(ls.rt), uniform(lq.beta), uniform(lq.dx), uniform(lq.dy),
                       uniform(lq.maxError), uniform(lq.nx), uniform(lq.ny), uniform(lq.maxit), word(2 * sub), change_word};
-      sor_pipe<0, PRE>(A, snap, W, P, M);
+      sor_pipe<0, true, FAST>(A, snap, W, P, M);
     }
     __syncthreads();
     {
@@ -1386,9 +1449,10 @@ extern "C" int nsk_bub_dns_step(nsk_ctx *ctx, const nsk_bub_dns_state *s, const 
   const PipePlan pl = pipe_plan(ctx, 0, nx, ny, q->maxit);
   if (ctx->bub_merge_launches && pl.ok && pl.pre) {
     if (int rc = pipe_reserve(ctx, pl, nx, ny)) return rc;
-    NSK_HIP(hipFuncSetAttribute((const void *)k_dns_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.pbytes));
-    k_dns_step<true><<<1, merged_threads(pl, nx, ny), pl.pbytes, ctx->stream>>>(*s, *q, ctx->sor_snap, pl.W, pl.P, pl.M, step_word(ctx, 0),
-                                                                        reinterpret_cast<double *>(ctx->red_dev + 3));
+    const auto kernel = pl.fast ? k_dns_step<true> : k_dns_step<false>;
+    NSK_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.pbytes));
+    kernel<<<1, merged_threads(pl, nx, ny), pl.pbytes, ctx->stream>>>(*s, *q, ctx->sor_snap, pl.W, pl.P, pl.M, step_word(ctx, 0),
+                                                                      reinterpret_cast<double *>(ctx->red_dev + 3));
     NSK_LAUNCH_CHECK();
     if (sweeps_out) {
       NSK_HIP(hipMemcpyAsync(ctx->red_host + 8, ctx->red_dev + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1437,10 +1501,11 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
     if (front_bytes > lds_bytes) lds_bytes = front_bytes;
     if (ctx->bub_merge_launches && plp.ok && plp.pre && pld.ok && lds_bytes <= 156 * 1024) {
       if (int rc = pipe_reserve(ctx, plp, nx, ny)) return rc;
-      NSK_HIP(hipFuncSetAttribute((const void *)k_code3_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      k_code3_step<true><<<1, merged_threads(plp, nx, ny), lds_bytes, ctx->stream>>>(*s, *q, ctx->sor_snap, plp.W, plp.P, plp.M,
-                                                                             reinterpret_cast<unsigned long long *>(step_word(ctx, 0)),
-                                                                             reinterpret_cast<double *>(ctx->red_dev + 3));
+      const auto kernel = plp.fast ? k_code3_step<true> : k_code3_step<false>;
+      NSK_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      kernel<<<1, merged_threads(plp, nx, ny), lds_bytes, ctx->stream>>>(*s, *q, ctx->sor_snap, plp.W, plp.P, plp.M,
+                                                                         reinterpret_cast<unsigned long long *>(step_word(ctx, 0)),
+                                                                         reinterpret_cast<double *>(ctx->red_dev + 3));
       NSK_LAUNCH_CHECK();
       NSK_HIP(hipMemcpyAsync(ctx->red_host + 8, ctx->red_dev + 8, 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
       NSK_HIP(hipStreamSynchronize(ctx->stream));

@@ -119,6 +119,10 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
     ctx->sor_pipeline = value != 0;
     return 0;
   }
+  if (!strcmp(name, "sor_fast_division")) {
+    ctx->sor_fast_division = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "bub_merge_launches")) {
     ctx->bub_merge_launches = value != 0;
     return 0;
@@ -168,6 +172,10 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   }
   if (!strcmp(name, "sor_pipeline")) {
     *value = ctx->sor_pipeline;
+    return 0;
+  }
+  if (!strcmp(name, "sor_fast_division")) {
+    *value = ctx->sor_fast_division;
     return 0;
   }
   if (!strcmp(name, "bub_merge_launches")) {

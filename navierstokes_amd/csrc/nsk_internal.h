@@ -46,6 +46,7 @@ struct nsk_ctx {
   // nsk_ns_poisson_iters_edges_first (created on first use): fork and edge-rows-final events
   hipEvent_t ev_fork = nullptr, ev_edge = nullptr;
   int bub_merge_launches = 1;  // bubble time steps: 1 = element-wise kernels as phases of the solver launches on grids one workgroup holds
+  int sor_fast_division = 1;  // sweeps-in-flight pressure solve: exact division through reciprocals (IEEE rerun when out of range)
   int sor_pipeline = 1;  // lexicographic SOR: 1 = several sweeps in flight when everything fits LDS, 0 = one at a time
   double *sor_snap = nullptr;  // per-sweep snapshots of the unknown for that kernel
   size_t sor_snap_elems = 0;

@@ -9,7 +9,7 @@ import pytest
 
 from navierstokes_amd.bubble import Code3, Code3Params, DNS, DNSParams, cell_centres, front_circle
 from oracle.bubble_oracle import BubbleOracle, OracleCode3, OracleDNS
-from util import Dev, same_bits
+from util import Dev, same_bits, strict_bits
 
 pytestmark = pytest.mark.gpu
 GRIDS = [(2, 2), (5, 3), (32, 32), (70, 45), (129, 200)]
@@ -227,39 +227,63 @@ def test_scalable_pressure_solvers(gpu, bo, nx, ny):
 
 @pytest.mark.parametrize("nx,ny", [(2, 2), (3, 7), (31, 33), (32, 32), (33, 20), (64, 64), (66, 60), (70, 45)])
 def test_sor_sweeps_in_flight(gpu, bo, nx, ny):
-    """The lexicographic SOR with several sweeps in flight (grids that fit LDS) and with one sweep at
-    a time give the oracle's values, sweep count and last change: every stopping point from the
-    first sweep to one past a full round of slots, tolerance met early, late and never, NaN."""
+    """The lexicographic SOR with several sweeps in flight (grids that fit LDS; with the quotients
+    through reciprocals and with IEEE divisions) and with one sweep at a time give the oracle's
+    values, sweep count and last change: every stopping point from the first sweep to one past a
+    full round of groups, tolerance met early, late and never, and the operands the reciprocal
+    form hands back to the IEEE division: NaN, infinities, zeros of either sign, subnormal and
+    huge pressures, density sums outside [2^-100, 2^100] and of the wrong sign."""
     rng = np.random.default_rng(nx * 977 + ny)
     dx, dy = 1.0 / nx, 1.3 / ny
     rt, t2 = rf(rng, nx + 2, ny + 2, 1.0), rf(rng, nx + 2, ny + 2, 0.01)
     t1, fx, fy = rf(rng, nx + 2, ny + 2), rf(rng, nx + 2, ny + 2), rf(rng, nx + 2, ny + 2)
     t2 *= dx * dx
     p0 = rf(rng, nx + 2, ny + 2)
-    pnan = p0.copy(order="F")
-    pnan[1, 1] = np.nan
+
+    def variant(fill, count=3):
+        a = p0.copy(order="F")
+        for v in np.atleast_1d(fill):
+            for _ in range(count):
+                a[rng.integers(0, nx + 2), rng.integers(0, ny + 2)] = v
+        return a
+
+    pnan = variant(np.nan, 1)
+    pzero = np.asfortranarray(np.where(rng.random(p0.shape) < 0.5, 0.0, -0.0))
+    pzero[nx // 2 + 1, ny // 2 + 1] = 1.0
+    specials = [pnan, variant(np.inf, 1), pzero, variant([0.0, -0.0]), variant([3e-310, -5e-324]), variant([1e290, -1e305]),
+                variant([1e-280, -1e-300])]
+    rt_tiny, rt_huge, rt_neg = rt * 1e-45, rt * 1e40, rt.copy(order="F")
+    rt_neg[(nx + 2) // 2, (ny + 2) // 2] = -3.0
     drt, dt1, dt2, dfx, dfy = Dev(rt), Dev(t1), Dev(t2), Dev(fx), Dev(fy)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    cases = [(m, 0.0, p0) for m in (1, 2, 3, 4, 15, 16, 17, 31, 32, 33, 34, 65, 97)]
-    cases += [(400, 1e-2, p0), (400, 1e-5, p0), (40, 1e-300, p0), (37, 1e-3, pnan)]
+    cases = [(m, 0.0, p0, rt) for m in (1, 2, 3, 4, 15, 16, 17, 31, 32, 33, 34, 65, 97)]
+    cases += [(400, 1e-2, p0, rt), (400, 1e-5, p0, rt), (40, 1e-300, p0, rt)]
+    cases += [(37, 1e-3, start, rt) for start in specials]
+    cases += [(23, 1e-3, p0, other) for other in (rt_tiny, rt_huge, rt_neg)]
     try:
-        for pipe in (1, 0):
+        for pipe, fast in ((1, 1), (1, 0), (0, 1)):
             gpu.set_option("sor_pipeline", pipe)
-            for maxit, tol, start in cases:
+            gpu.set_option("sor_fast_division", fast)
+            for n, (maxit, tol, start, dens) in enumerate(cases):
+                what = (pipe, fast, n, maxit, tol)
+                ddens = drt if dens is rt else Dev(dens)
                 p, dp_ = start.copy(order="F"), Dev(start)
                 sw, ch, chr_ = C.c_int(0), C.c_double(0.0), C.c_double(0.0)
-                gpu.bub_solve_pressure(dp_.ptr, dt1.ptr, dt2.ptr, drt.ptr, 1.2, dx, dy, nx, ny, maxit, tol, C.byref(sw), C.byref(ch))
-                it = bo.lib.bub_solve_pressure(vp(p), vp(t1), vp(t2), vp(rt), C.c_double(1.2), C.c_double(dx), C.c_double(dy), nx, ny, maxit,
+                gpu.bub_solve_pressure(dp_.ptr, dt1.ptr, dt2.ptr, ddens.ptr, 1.2, dx, dy, nx, ny, maxit, tol, C.byref(sw), C.byref(ch))
+                it = bo.lib.bub_solve_pressure(vp(p), vp(t1), vp(t2), vp(dens), C.c_double(1.2), C.c_double(dx), C.c_double(dy), nx, ny, maxit,
                                                C.c_double(tol), C.byref(chr_))
-                assert sw.value == it, (pipe, maxit, tol, sw.value, it)
-                assert same_bits(np.array([ch.value]), np.array([chr_.value])), (pipe, maxit, tol)
-                assert same_bits(dp_.get(), p), (pipe, maxit, tol)
+                assert sw.value == it, (what, sw.value, it)
+                assert strict_bits(np.array([ch.value]), np.array([chr_.value])), what
+                assert strict_bits(dp_.get(), p), what
+                if dens is not rt or fast == 0:
+                    continue
                 r, dr = start.copy(order="F"), Dev(start)
                 gpu.bub_construct_den(dr.ptr, dfx.ptr, dfy.ptr, 1.2, maxit, tol, dx, dy, nx, ny, C.byref(sw))
                 it = bo.construct_den(r, fx, fy, 1.2, maxit, tol, dx, dy, nx, ny)
-                assert sw.value == it and same_bits(dr.get(), r), (pipe, maxit, tol, sw.value, it)
+                assert sw.value == it and same_bits(dr.get(), r), (what, sw.value, it)
     finally:
         gpu.set_option("sor_pipeline", 1)
+        gpu.set_option("sor_fast_division", 1)
 
 
 def test_solver_nan_runs_to_maxit(gpu, bo):

@@ -36,6 +36,15 @@ def same_bits(a: np.ndarray, b: np.ndarray) -> bool:
     return bool(np.array_equal(a, b, equal_nan=True))
 
 
+def strict_bits(a: np.ndarray, b: np.ndarray) -> bool:
+    """Equal bit patterns (the sign of a zero counts), NaNs in the same places."""
+    a, b = np.ascontiguousarray(a, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)
+    if a.shape != b.shape:
+        return False
+    na, nb = np.isnan(a), np.isnan(b)
+    return bool(np.array_equal(na, nb) and np.array_equal(a.view(np.uint64)[~na], b.view(np.uint64)[~nb]))
+
+
 def rel_l2(a, b) -> float:
     d = np.linalg.norm((a - b).ravel())
     n = np.linalg.norm(b.ravel())
