@@ -405,127 +405,136 @@ __device__ __forceinline__ void sor_pipe(const SorArgs &A, double *snap, int W, 
   double *rfx = fy + ncell, *rfy = rfx + ncell;  // FAST
   unsigned long long *sweep_max = reinterpret_cast<unsigned long long *>(lds + (size_t)NARR * ncell);  // [R]
   int *unsafe = reinterpret_cast<int *>(sweep_max + R);  // FAST: somebody met an operand the fast division does not cover
-  bool fast = FAST;
-  int final_sweep;
-  unsigned long long last;
-  for (;;) {  // a second round only after the fast division has met such an operand
-  bool bad = false;
-  for (int k = tid; k < ncell; k += nth) {
-    const double ak = A.a[k];
-    a[k] = ak;
-    if (FAST) bad |= !fast_dividend_ok(ak);
-    if (MODE == 0) {
-      c1[k] = A.c1[k];
-      c2[k] = beta * A.c2[k];
-      if (!PRE) {
-        rt[k] = A.c3[k];
-      } else {
-        const int i0 = k % ld, j0 = k / ld;  // 0-based
-        const double dxf = i0 + 1 < ld ? dx * (A.c3[k + 1] + A.c3[k]) : 0.0;
-        const double dyf = j0 + 1 < ny + 2 ? dy * (A.c3[k + ld] + A.c3[k]) : 0.0;
-        fxd[k] = dxf;
-        fy[k] = dyf;
-        if (FAST) {
-          rfx[k] = 1.0 / dxf;
-          rfy[k] = 1.0 / dyf;
-          // the faces of interior cells are the ones that divide
-          if (i0 <= nx && j0 >= 1 && j0 <= ny) bad |= !fast_divisor_ok(dxf);
-          if (j0 <= ny && i0 >= 1 && i0 <= nx) bad |= !fast_divisor_ok(dyf);
-        }
-      }
-    } else {
-      c1[k] = dx * A.c1[k];
-      c2[k] = dy * A.c2[k];
-    }
-  }
-  for (int k = tid; k < R; k += nth) sweep_max[k] = 0;
-  if (FAST && tid == 0) *unsafe = 0;
-  __syncthreads();
-  const int ND = nx + ny - 1;
-  const int w = tid / nx, ci = tid - w * nx;  // this thread's group and column (0-based)
-  const bool alive = w < W;
-  int r = -(2 * w + ci);                      // this thread's row (0-based; negative: not started)
-  int k = w + 1, ks = k == R ? 0 : k;         // its sweep, and the sweep modulo R
-  int q = ld + ci + 1;                        // its cell; q +- 1, q +- ld the neighbours
-  double *my_snap = snap + (size_t)ks * ncell;
-  int c = -(ND - 1), batch = 0, bm = 0;       // step counter of the completion test, see below
-  unsigned long long mymax = 0;
-  last = 0;
-  final_sweep = A.maxit;
-  // every sweep up to maxit is complete after this many steps; the loop ends earlier by itself
-  const long long step_limit = ((long long)A.maxit / W + 2) * P + 2 * W + ND;
-  for (long long t = 0; t < step_limit; t++) {
-    if (alive && r >= 0 && r < ny && k <= A.maxit) {
-      if (r == 0) {
-        mymax = 0;
-        // the word's previous sweep was judged at least two steps ago
-        if (ci == 0) sweep_max[ks] = 0;
-      }
-      const double old = a[q];
-      double nw;
+  int final_sweep = A.maxit;
+  unsigned long long last = 0;
+  // One run of the whole solve from its inputs; returns whether anybody met an operand the fast
+  // division does not cover (the result is then discarded and the solve run again with IEEE divisions).
+  auto solve = [&](auto fast_tag) -> bool {
+    constexpr bool fast = decltype(fast_tag)::value;
+    bool bad = false;
+    for (int k = tid; k < ncell; k += nth) {
+      const double ak = A.a[k];
+      a[k] = ak;
+      if (fast) bad |= !fast_dividend_ok(ak);
       if (MODE == 0) {
-        double ex, ey;  // the two brackets of code1.m:70-73
-        if (FAST && fast) {
-          ex = fast_div(a[q + 1], fxd[q], rfx[q]) + fast_div(a[q - 1], fxd[q - 1], rfx[q - 1]);
-          ey = fast_div(a[q + ld], fy[q], rfy[q]) + fast_div(a[q - ld], fy[q - ld], rfy[q - ld]);
-        } else if (PRE) {
-          ex = a[q + 1] / fxd[q] + a[q - 1] / fxd[q - 1];
-          ey = a[q + ld] / fy[q] + a[q - ld] / fy[q - ld];
+        c1[k] = A.c1[k];
+        c2[k] = beta * A.c2[k];
+        if (!PRE) {
+          rt[k] = A.c3[k];
         } else {
-          ex = a[q + 1] / (dx * (rt[q + 1] + rt[q])) + a[q - 1] / (dx * (rt[q - 1] + rt[q]));
-          ey = a[q + ld] / (dy * (rt[q + ld] + rt[q])) + a[q - ld] / (dy * (rt[q - ld] + rt[q]));
+          const int i0 = k % ld, j0 = k / ld;  // 0-based
+          const double dxf = i0 + 1 < ld ? dx * (A.c3[k + 1] + A.c3[k]) : 0.0;
+          const double dyf = j0 + 1 < ny + 2 ? dy * (A.c3[k + ld] + A.c3[k]) : 0.0;
+          fxd[k] = dxf;
+          fy[k] = dyf;
+          if (fast) {
+            rfx[k] = 1.0 / dxf;
+            rfy[k] = 1.0 / dyf;
+            // the faces of interior cells are the ones that divide
+            if (i0 <= nx && j0 >= 1 && j0 <= ny) bad |= !fast_divisor_ok(dxf);
+            if (j0 <= ny && i0 >= 1 && i0 <= nx) bad |= !fast_divisor_ok(dyf);
+          }
         }
-        nw = (1.0 - beta) * old + c2[q] * ((1.0 / dx) * ex + (1.0 / dy) * ey - c1[q]);
       } else {
-        nw = (1.0 - beta) * old +
-             beta * (0.25 * (a[q + 1] + a[q - 1] + a[q + ld] + a[q - ld] + c1[q - 1] - c1[q] + c2[q - ld] - c2[q]));
+        c1[k] = dx * A.c1[k];
+        c2[k] = dy * A.c2[k];
       }
-      a[q] = nw;
-      my_snap[q] = nw;
-      if (FAST) bad |= !fast_dividend_ok(nw);
-      const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(old - nw));
-      mymax = b > mymax ? b : mymax;
-      q += ld;
-      // top of the column: its max|old-new| (integer max of the bit patterns keeps NaN)
-      if (r == ny - 1) atomicMax(&sweep_max[ks], mymax);
     }
-    if (++r == P) {
-      r = 0;
-      q = ld + ci + 1;
-      k += W;
-      ks += W;
-      if (ks >= R) ks -= R;
-      my_snap = snap + (size_t)ks * ncell;
-    }
-    __syncthreads();  // the step's values and, if a sweep ended, its maximum are visible to everybody
-    // Group g completes a sweep at steps 2g + ND-1 + b P: c counts steps from ND-1 modulo P, so an
-    // even c below 2W names the group (at most one per step), `batch` its b, bm = b modulo M.
-    if (c >= 0 && !(c & 1) && (c >> 1) < W) {
-      const int kc = batch * W + (c >> 1) + 1;
-      if (kc <= A.maxit) {
-        int idx = bm * W + (c >> 1) + 1;
-        if (idx == R) idx = 0;
-        last = sweep_max[idx];
-        const double ch = __longlong_as_double((long long)last);
-        if (ch < A.maxError || kc == A.maxit) {  // (false for NaN: keeps sweeping, as the reference does)
-          final_sweep = kc;
-          break;
+    for (int k = tid; k < R; k += nth) sweep_max[k] = 0;
+    if (fast && tid == 0) *unsafe = 0;
+    __syncthreads();
+    const int ND = nx + ny - 1;
+    const int w = tid / nx, ci = tid - w * nx;  // this thread's group and column (0-based)
+    const bool alive = w < W;
+    int r = -(2 * w + ci);                      // this thread's row (0-based; negative: not started)
+    int k = w + 1, ks = k == R ? 0 : k;         // its sweep, and the sweep modulo R
+    int q = ld + ci + 1;                        // its cell; q +- 1, q +- ld the neighbours
+    double *my_snap = snap + (size_t)ks * ncell;
+    int c = -(ND - 1), batch = 0, bm = 0;       // step counter of the completion test, see below
+    unsigned long long mymax = 0;
+    last = 0;
+    final_sweep = A.maxit;
+    // every sweep up to maxit is complete after this many steps; the loop ends earlier by itself
+    const long long step_limit = ((long long)A.maxit / W + 2) * P + 2 * W + ND;
+    for (long long t = 0; t < step_limit; t++) {
+      if (alive && r >= 0 && r < ny && k <= A.maxit) {
+        // everything the cell needs is asked of LDS at once, ahead of any branch
+        const double old = a[q], east = a[q + 1], west = a[q - 1], north = a[q + ld], south = a[q - ld];
+        double nw;
+        if (MODE == 0) {
+          const double s1 = c1[q], s2 = c2[q];
+          double ex, ey;  // the two brackets of code1.m:70-73
+          if (PRE) {
+            const double de = fxd[q], dw = fxd[q - 1], dn = fy[q], ds = fy[q - ld];
+            if (fast) {
+              const double re = rfx[q], rw = rfx[q - 1], rn = rfy[q], rs = rfy[q - ld];
+              ex = fast_div(east, de, re) + fast_div(west, dw, rw);
+              ey = fast_div(north, dn, rn) + fast_div(south, ds, rs);
+            } else {
+              ex = east / de + west / dw;
+              ey = north / dn + south / ds;
+            }
+          } else {
+            const double rc = rt[q], re = rt[q + 1], rw = rt[q - 1], rn = rt[q + ld], rs = rt[q - ld];
+            ex = east / (dx * (re + rc)) + west / (dx * (rw + rc));
+            ey = north / (dy * (rn + rc)) + south / (dy * (rs + rc));
+          }
+          nw = (1.0 - beta) * old + s2 * ((1.0 / dx) * ex + (1.0 / dy) * ey - s1);
+        } else {
+          nw = (1.0 - beta) * old + beta * (0.25 * (east + west + north + south + c1[q - 1] - c1[q] + c2[q - ld] - c2[q]));
+        }
+        a[q] = nw;
+        my_snap[q] = nw;
+        if (fast) bad |= !fast_dividend_ok(nw);
+        const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(old - nw));
+        mymax = (r == 0 || b > mymax) ? b : mymax;  // a new column starts a new maximum
+        // the word's previous sweep was judged at least two steps ago
+        if (r == 0 && ci == 0) sweep_max[ks] = 0;
+        q += ld;
+        // top of the column: its max|old-new| (integer max of the bit patterns keeps NaN)
+        if (r == ny - 1) atomicMax(&sweep_max[ks], mymax);
+      }
+      if (++r == P) {
+        r = 0;
+        q = ld + ci + 1;
+        k += W;
+        ks += W;
+        if (ks >= R) ks -= R;
+        my_snap = snap + (size_t)ks * ncell;
+      }
+      __syncthreads();  // the step's values and, if a sweep ended, its maximum are visible to everybody
+      // Group g completes a sweep at steps 2g + ND-1 + b P: c counts steps from ND-1 modulo P, so an
+      // even c below 2W names the group (at most one per step), `batch` its b, bm = b modulo M.
+      if (c >= 0 && !(c & 1) && (c >> 1) < W) {
+        const int kc = batch * W + (c >> 1) + 1;
+        if (kc <= A.maxit) {
+          int idx = bm * W + (c >> 1) + 1;
+          if (idx == R) idx = 0;
+          last = sweep_max[idx];
+          const double ch = __longlong_as_double((long long)last);
+          if (ch < A.maxError || kc == A.maxit) {  // (false for NaN: keeps sweeping, as the reference does)
+            final_sweep = kc;
+            break;
+          }
         }
       }
+      if (++c == P) {
+        c = 0;
+        batch++;
+        if (++bm == M) bm = 0;
+      }
     }
-    if (++c == P) {
-      c = 0;
-      batch++;
-      if (++bm == M) bm = 0;
-    }
-  }
-  if (!FAST || !fast) break;
-  if (bad) *unsafe = 1;
-  __syncthreads();
-  const bool again = *unsafe != 0;
-  __syncthreads();  // everybody has read the flag before the next round clears it
-  if (!again) break;
-  fast = false;
+    if (!fast) return false;
+    if (bad) *unsafe = 1;
+    __syncthreads();
+    const bool again = *unsafe != 0;
+    __syncthreads();  // everybody has read the flag before the next round clears it
+    return again;
+  };
+  if (FAST) {
+    if (solve(std::true_type{})) solve(std::false_type{});
+  } else {
+    solve(std::false_type{});
   }
   // interior cells of the final sweep's snapshot (ghost cells are never written by a sweep)
   const double *fin = snap + (size_t)(final_sweep % R) * ncell;

@@ -17,9 +17,15 @@ ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
 rng = np.random.default_rng(1)
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
 shape = (nx + 2, ny + 2)
-p0 = dev(rng.standard_normal(shape))
-t1, t2, rt = dev(rng.standard_normal(shape)), dev(0.01 + rng.random(shape) / nx ** 2), dev(1.0 + rng.random(shape))
 ptr = lambda t: C.c_void_p(t.data_ptr())
+p0 = dev(rng.standard_normal(shape))
+# coefficients of a real solve (the iteration contracts): densities 1..2 with the large value on the
+# border, sources from random temporary velocities
+r, rt = dev(1.0 + rng.random(shape)), dev(np.zeros(shape))
+t1, t2 = dev(np.zeros(shape)), dev(np.zeros(shape))
+ut, vt = dev(rng.standard_normal((nx + 1, ny + 2))), dev(rng.standard_normal((nx + 2, ny + 1)))
+ctx.bub_set_boundary(ptr(rt), ptr(r), 1000.0, nx, ny)
+ctx.bub_compute_sources(ptr(t1), ptr(t2), ptr(rt), ptr(ut), ptr(vt), 0.00125, 1.0 / nx, 1.0 / ny, nx, ny)
 for pipe in (1, 0):
     ctx.set_option("sor_pipeline", pipe)
     for sweeps in (8, 50, 400):
