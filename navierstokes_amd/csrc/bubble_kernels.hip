@@ -1460,11 +1460,12 @@ extern "C" int nsk_bub_dns_step(nsk_ctx *ctx, const nsk_bub_dns_state *s, const 
     if (int rc = pipe_reserve(ctx, pl, nx, ny)) return rc;
     const auto kernel = pl.fast ? k_dns_step<true> : k_dns_step<false>;
     NSK_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.pbytes));
-    kernel<<<1, merged_threads(pl, nx, ny), pl.pbytes, ctx->stream>>>(*s, *q, ctx->sor_snap, pl.W, pl.P, pl.M, step_word(ctx, 0),
+    // the sweep count goes straight to the pinned host word (device-visible): no copy command to wait for
+    int *word = sweeps_out ? reinterpret_cast<int *>(ctx->red_host + 8) : step_word(ctx, 0);
+    kernel<<<1, merged_threads(pl, nx, ny), pl.pbytes, ctx->stream>>>(*s, *q, ctx->sor_snap, pl.W, pl.P, pl.M, word,
                                                                       reinterpret_cast<double *>(ctx->red_dev + 3));
     NSK_LAUNCH_CHECK();
     if (sweeps_out) {
-      NSK_HIP(hipMemcpyAsync(ctx->red_host + 8, ctx->red_dev + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
       NSK_HIP(hipStreamSynchronize(ctx->stream));
       *sweeps_out = host_word(ctx, 0);
     }
@@ -1512,11 +1513,10 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
       if (int rc = pipe_reserve(ctx, plp, nx, ny)) return rc;
       const auto kernel = plp.fast ? k_code3_step<true> : k_code3_step<false>;
       NSK_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      kernel<<<1, merged_threads(plp, nx, ny), lds_bytes, ctx->stream>>>(*s, *q, ctx->sor_snap, plp.W, plp.P, plp.M,
-                                                                         reinterpret_cast<unsigned long long *>(step_word(ctx, 0)),
+      // sweep counts and front size go straight to the pinned host words (device-visible)
+      kernel<<<1, merged_threads(plp, nx, ny), lds_bytes, ctx->stream>>>(*s, *q, ctx->sor_snap, plp.W, plp.P, plp.M, ctx->red_host + 8,
                                                                          reinterpret_cast<double *>(ctx->red_dev + 3));
       NSK_LAUNCH_CHECK();
-      NSK_HIP(hipMemcpyAsync(ctx->red_host + 8, ctx->red_dev + 8, 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
       NSK_HIP(hipStreamSynchronize(ctx->stream));
       const int nf_new = host_word(ctx, 4);
       NSK_REQUIRE(nf_new >= 0, "nsk_bub_code3_step: the front outgrew its capacity of %d points", s->cap);

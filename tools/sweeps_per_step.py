@@ -1,17 +1,29 @@
-import sys, time
-sys.path.insert(0, '/root/repo')
-import torch
-from navierstokes_amd.bubble import DNS, DNSParams, Code3, Code3Params
-g = DNS(DNSParams())
-for _ in range(20): g.step()
-torch.cuda.synchronize(); t=time.time(); sw=[]
-for _ in range(200): sw.append(g.step())
-torch.cuda.synchronize(); dt=(time.time()-t)/200
-print("DNS: mean sweeps", sum(sw)/len(sw), "us/step", dt*1e6, "steps of pipeline", 63+2*(sum(sw)/len(sw)-1))
-g = Code3(Code3Params())
-for _ in range(20): g.step()
-torch.cuda.synchronize(); t=time.time(); sw=[]
-for _ in range(100): sw.append(g.step())
-torch.cuda.synchronize(); dt=(time.time()-t)/100
+#!/usr/bin/env python3
+"""Steady-state cost of a time step of the two bubble drivers at the reference sizes: mean sweeps
+per lexicographic SOR solve and microseconds per step, after the start-up transient."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-print("code3: mean sweeps", np.mean(np.array(sw),axis=0), "us/step", dt*1e6)
+import torch
+
+from navierstokes_amd.bubble import Code3, Code3Params, DNS, DNSParams
+
+
+def run(sim, warm, steps):
+    for _ in range(warm):
+        sim.step()
+    torch.cuda.synchronize()
+    t0, sweeps = time.time(), []
+    for _ in range(steps):
+        sweeps.append(sim.step())
+    torch.cuda.synchronize()
+    return np.mean(np.array(sweeps, dtype=float), axis=0), (time.time() - t0) / steps * 1e6
+
+
+sw, us = run(DNS(DNSParams()), 20, 200)
+print(f"DNS.jl 32x32: {sw:.1f} sweeps per pressure solve = {63 + 2 * (sw - 1):.0f} barrier steps of the pipeline, {us:.1f} us per time step")
+sw, us = run(Code3(Code3Params()), 20, 100)
+print(f"code3 32x32, Nf=100: sweeps per solve (pressure, density, pressure, density) {np.round(sw, 1)}, {us:.1f} us per time step")
