@@ -5,10 +5,11 @@
  * for |x| in [2^-900, 2^900] or zero and d in [2^-100, 2^100] (no intermediate leaves the normal
  * range there).  q1 is a faithful rounding of x/d whatever the error of q0, so the last step is
  * Markstein's correction.  Random operands plus quotients placed next to rounding boundaries.
- *   gcc -O2 -ffp-contract=off -o fma_division_check fma_division_check.c -lm && ./fma_division_check */
+ *   gcc -O2 -ffp-contract=off -mfma -o fma_division_check fma_division_check.c -lm && ./fma_division_check [percent of the cases] */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 static uint64_t s[2] = {0x9E3779B97F4A7C15ull, 0xD1B54A32D192ED03ull};
@@ -45,16 +46,15 @@ static void check(double x, double d) {
     bad++;
   }
 }
-int main(void) {
-  for (long k = 0; k < 100000000L; k++) check(rnd_double(-900, 900, 1), rnd_double(-100, 100, 0));
+int main(int argc, char **argv) {
+  const long pc = argc > 1 ? atol(argv[1]) : 100;
+  for (long k = 0; k < 1000000L * pc; k++) check(rnd_double(-900, 900, 1), rnd_double(-100, 100, 0));
   /* narrow exponent ranges: more ties and near-ties per case */
-  for (long k = 0; k < 100000000L; k++) check(rnd_double(-2, 2, 1), rnd_double(-2, 2, 0));
+  for (long k = 0; k < 1000000L * pc; k++) check(rnd_double(-2, 2, 1), rnd_double(-2, 2, 0));
   /* quotients next to a rounding boundary: x = RN((q + half an ulp) d) and its neighbours */
-  for (long k = 0; k < 30000000L; k++) {
+  for (long k = 0; k < 300000L * pc; k++) {
     const double d = rnd_double(-3, 3, 0), q = rnd_double(-3, 3, 1);
-    const double mid = q + 0.5 * (nextafter(q, INFINITY) - q);  /* not representable: rounds, but lands close */
     const double x0 = fma(q, d, 0.5 * (nextafter(q, INFINITY) - q) * d);
-    (void)mid;
     double x = x0;
     for (int j = -2; j <= 2; j++) {
       x = x0;
@@ -63,7 +63,7 @@ int main(void) {
     }
   }
   /* divisors with few bits, with all bits, powers of two; zeros of either sign */
-  for (long k = 0; k < 20000000L; k++) {
+  for (long k = 0; k < 200000L * pc; k++) {
     const double x = rnd_double(-900, 900, 1);
     check(x, (double)(1 + rnd() % 1000) * 0x1p-7);
     check(x, from_bits(bits(rnd_double(-100, 100, 0)) | 0xFFFFFFFFFFFFFull));
