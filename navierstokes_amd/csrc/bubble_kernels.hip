@@ -925,8 +925,7 @@ int launch_sor(nsk_ctx *ctx, int mode, double *a, const double *c1, const double
       const bool pre = pl.pre;
 #define NSK_PIPE(M_, P_, F_)                                                                                      \
   do {                                                                                                            \
-    NSK_HIP(hipFuncSetAttribute((const void *)k_sor_pipe<M_, P_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)pl.pbytes));                                                                 \
+    NSK_HIP(nsk_allow_lds(ctx, (const void *)k_sor_pipe<M_, P_, F_>, pl.pbytes));                                 \
     k_sor_pipe<M_, P_, F_><<<1, pl.nth, pl.pbytes, ctx->stream>>>(A, ctx->sor_snap, pl.W, pl.P, pl.M);            \
   } while (0)
       if (mode != 0) NSK_PIPE(1, false, false);
@@ -1459,7 +1458,7 @@ extern "C" int nsk_bub_dns_step(nsk_ctx *ctx, const nsk_bub_dns_state *s, const 
   if (ctx->bub_merge_launches && pl.ok && pl.pre) {
     if (int rc = pipe_reserve(ctx, pl, nx, ny)) return rc;
     const auto kernel = pl.fast ? k_dns_step<true> : k_dns_step<false>;
-    NSK_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.pbytes));
+    NSK_HIP(nsk_allow_lds(ctx, (const void *)kernel, pl.pbytes));
     // the sweep count goes straight to the pinned host word (device-visible): no copy command to wait for
     int *word = sweeps_out ? reinterpret_cast<int *>(ctx->red_host + 8) : step_word(ctx, 0);
     kernel<<<1, merged_threads(pl, nx, ny), pl.pbytes, ctx->stream>>>(*s, *q, ctx->sor_snap, pl.W, pl.P, pl.M, word,
@@ -1512,7 +1511,7 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
     if (ctx->bub_merge_launches && plp.ok && plp.pre && pld.ok && lds_bytes <= 156 * 1024) {
       if (int rc = pipe_reserve(ctx, plp, nx, ny)) return rc;
       const auto kernel = plp.fast ? k_code3_step<true> : k_code3_step<false>;
-      NSK_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      NSK_HIP(nsk_allow_lds(ctx, (const void *)kernel, lds_bytes));
       // sweep counts and front size go straight to the pinned host words (device-visible)
       kernel<<<1, merged_threads(plp, nx, ny), lds_bytes, ctx->stream>>>(*s, *q, ctx->sor_snap, plp.W, plp.P, plp.M, ctx->red_host + 8,
                                                                          reinterpret_cast<double *>(ctx->red_dev + 3));

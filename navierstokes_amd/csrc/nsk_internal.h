@@ -50,11 +50,37 @@ struct nsk_ctx {
   int sor_pipeline = 1;  // lexicographic SOR: 1 = several sweeps in flight when everything fits LDS, 0 = one at a time
   double *sor_snap = nullptr;  // per-sweep snapshots of the unknown for that kernel
   size_t sor_snap_elems = 0;
+  // Largest dynamic LDS size already allowed for a kernel through this context (the attribute call
+  // costs microseconds, a time step of the bubble drivers a hundred).
+  struct LdsAllowed {
+    const void *kernel;
+    size_t bytes;
+  } lds_allowed[16] = {};
   int step_fused = 1;    // nsk_ns_step: 1 = three fused kernels around the Poisson loop, 0 = one launch per call site
   int poisson_rows = 0;  // rows per task chunk, 0 = automatic (NSK_POISSON_ROWS / nsk_set_option)
 };
 
 void nsk_set_error(const char *fmt, ...);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) unless this context has already allowed the
+// kernel at least `bytes`.
+inline hipError_t nsk_allow_lds(nsk_ctx *ctx, const void *kernel, size_t bytes) {
+  nsk_ctx::LdsAllowed *slot = nullptr;
+  for (auto &e : ctx->lds_allowed) {
+    if (e.kernel == kernel) {
+      if (e.bytes >= bytes) return hipSuccess;
+      slot = &e;
+      break;
+    }
+    if (!e.kernel && !slot) slot = &e;
+  }
+  const hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (rc == hipSuccess && slot) {
+    slot->kernel = kernel;
+    slot->bytes = bytes;
+  }
+  return rc;
+}
 
 #define NSK_HIP(call)                                                          \
   do {                                                                         \
