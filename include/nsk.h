@@ -450,6 +450,15 @@ int nsk_bub_dns_step(nsk_ctx *ctx, const nsk_bub_dns_state *s, const nsk_bub_par
  * (may be NULL); s->Nf receives the regridded front size.  Synchronous. */
 int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const nsk_bub_params *q,
                        int *sweeps_out);
+/* The time loops themselves, scripts/DNS.jl:70-102 and scripts/code3_fun.jl:354-494 (without the
+ * plotting): nsteps time steps queued back to back, one wait at the end instead of one per step
+ * (code3's front size stays on the device in between).  sweeps_out receives the sweep counts of
+ * every step (nsteps values for DNS, 4 * nsteps for code3; may be NULL -- nsk_bub_dns_run then
+ * does not wait at all).  Same values as nsteps calls of the step functions. */
+int nsk_bub_dns_run(nsk_ctx *ctx, const nsk_bub_dns_state *s, const nsk_bub_params *q, int nsteps,
+                    int *sweeps_out);
+int nsk_bub_code3_run(nsk_ctx *ctx, nsk_bub_code3_state *s, const nsk_bub_params *q, int nsteps,
+                      int *sweeps_out);
 
 #ifdef __cplusplus
 }

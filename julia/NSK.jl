@@ -284,6 +284,19 @@ function code3_step!(c, s::Code3State, q::BubParams)
     check(ccall((:nsk_bub_code3_step, lib), Cint, (Ptr{Cvoid}, Ref{Code3State}, Ref{BubParams}, Ptr{Cint}), c.h, r, q, sw))
     r[], sw
 end
+"nsteps time steps of DNS.jl:70-102 queued in one call, one wait at its end; returns the sweeps of every step."
+function dns_run!(c, s::DnsState, q::BubParams, nsteps::Integer)
+    sw = zeros(Cint, nsteps)
+    check(ccall((:nsk_bub_dns_run, lib), Cint, (Ptr{Cvoid}, Ref{DnsState}, Ref{BubParams}, Cint, Ptr{Cint}), c.h, s, q, nsteps, sw))
+    sw
+end
+"nsteps time steps of code3_fun.jl:354-494 in one call; returns the state with the new front size and a 4 x nsteps matrix of sweep counts."
+function code3_run!(c, s::Code3State, q::BubParams, nsteps::Integer)
+    r = Ref(s)
+    sw = zeros(Cint, 4, nsteps)
+    check(ccall((:nsk_bub_code3_run, lib), Cint, (Ptr{Cvoid}, Ref{Code3State}, Ref{BubParams}, Cint, Ptr{Cint}), c.h, r, q, nsteps, sw))
+    r[], sw
+end
 
 # ---- bubble / drop solvers: scripts/DNS.jl (in the form scripts/code1.m states) and ----------
 # ---- scripts/code3_fun.jl; one stub per kernel, argument order of the Julia kernels ----------

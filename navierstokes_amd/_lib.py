@@ -111,6 +111,8 @@ _SIGS = {
     "nsk_ns_poisson_iters": [_P, _P, _P, C.POINTER(CNSParams), _I],
     "nsk_bub_dns_step": [C.POINTER(CDnsState), C.POINTER(CBubParams), C.POINTER(C.c_int)],
     "nsk_bub_code3_step": [C.POINTER(CCode3State), C.POINTER(CBubParams), C.POINTER(C.c_int)],
+    "nsk_bub_dns_run": [C.POINTER(CDnsState), C.POINTER(CBubParams), _I, C.POINTER(C.c_int)],
+    "nsk_bub_code3_run": [C.POINTER(CCode3State), C.POINTER(CBubParams), _I, C.POINTER(C.c_int)],
     "nsk_ns_poisson_iters_static": [_P, _P, _P, C.POINTER(CNSParams), _I],
     "nsk_ns_poisson_iters_edges_first": [_P, _P, _P, C.POINTER(CNSParams), _I, _I, _I, _I, _I, _P],
     "nsk_ns_residual": [_P, _P, _P, C.POINTER(CNSParams), _I, _I, c_double_p],

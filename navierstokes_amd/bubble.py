@@ -127,17 +127,36 @@ class DNS:
         # False: one C call per kernel, as the reference's driver is written
         self.fused = True
 
+    def _c_args(self):
+        q = self.q
+        st = _lib.CDnsState(u=self.u.ptr, v=self.v.ptr, p=self.p.ptr, ut=self.ut.ptr, vt=self.vt.ptr,
+                            tmp1=self.tmp1.ptr, tmp2=self.tmp2.ptr, r=self.rho.ptr, ro=self.rho_o.ptr,
+                            rt=self.rhot.ptr, uu=self.uu.ptr, vv=self.vv.ptr)
+        pr = _lib.CBubParams(nx=q.nx, ny=q.ny, maxit=q.maxit, Lx=q.Lx, Ly=q.Ly, gx=q.gx, gy=q.gy, rho1=q.rho1,
+                             rho2=q.rho2, m1=q.m0, m2=0.0, sigma=0.0, rro=0.0, usouth=q.usouth, unorth=q.unorth,
+                             vwest=q.vwest, veast=q.veast, dt=q.dt, dx=q.dx, dy=q.dy, maxError=q.maxerr, beta=q.beta)
+        return st, pr
+
+    def run(self, nsteps: int):
+        """nsteps time steps (the loop DNS.jl:70-102) in one C call with one wait at its end; the sweeps of
+        every step.  Other pressure solvers than the lexicographic SOR: a loop over step()."""
+        if not (self.fused and self.q.pressure_solver == "sor"):
+            return [self.step() for _ in range(nsteps)]
+        st, pr = self._c_args()
+        sw = (C.c_int * max(nsteps, 1))()
+        self.ctx.bub_dns_run(C.byref(st), C.byref(pr), nsteps, sw)
+        self.time += nsteps * self.q.dt
+        out = list(sw)[:nsteps]
+        if out:
+            self.sweeps = out[-1]
+        return out
+
     def step(self) -> int:
         """DNS.jl:71-101."""
         q, k, nx, ny = self.q, self.ctx, self.q.nx, self.q.ny
         self.time += q.dt
         if self.fused and q.pressure_solver == "sor":
-            st = _lib.CDnsState(u=self.u.ptr, v=self.v.ptr, p=self.p.ptr, ut=self.ut.ptr, vt=self.vt.ptr,
-                                tmp1=self.tmp1.ptr, tmp2=self.tmp2.ptr, r=self.rho.ptr, ro=self.rho_o.ptr,
-                                rt=self.rhot.ptr, uu=self.uu.ptr, vv=self.vv.ptr)
-            pr = _lib.CBubParams(nx=nx, ny=ny, maxit=q.maxit, Lx=q.Lx, Ly=q.Ly, gx=q.gx, gy=q.gy, rho1=q.rho1,
-                                 rho2=q.rho2, m1=q.m0, m2=0.0, sigma=0.0, rro=0.0, usouth=q.usouth, unorth=q.unorth,
-                                 vwest=q.vwest, veast=q.veast, dt=q.dt, dx=q.dx, dy=q.dy, maxError=q.maxerr, beta=q.beta)
+            st, pr = self._c_args()
             sw = C.c_int(0)
             k.bub_dns_step(C.byref(st), C.byref(pr), C.byref(sw))
             self.sweeps = sw.value
@@ -175,8 +194,11 @@ def dns_main(do_vis: bool = True, do_save: bool = False, *, q: DNSParams = DNSPa
     from scipy.io import savemat
     sim = DNS(q, device)
     nstep = 1
-    for it in range(1, q.nsteps + 1):
-        sim.step()
+    it = 0
+    while it < q.nsteps:
+        chunk = min(q.nvis - it % q.nvis, q.nsteps - it)  # up to the next output
+        sim.run(chunk)
+        it += chunk
         if it % q.nvis == 0:
             if do_save:
                 os.makedirs(out_dir, exist_ok=True)
@@ -273,16 +295,36 @@ class Code3:
         self.sweeps = [0, 0, 0, 0]
         self.fused = True            # one C call per time step (nsk_bub_code3_step) / one per kernel
 
+    def _c_args(self):
+        q = self.q
+        st = _lib.CCode3State(**{n: getattr(self, n).ptr for n in self.GRID + self.FRONT}, Nf=self.Nf, cap=q.cap)
+        pr = _lib.CBubParams(nx=q.nx, ny=q.ny, maxit=q.maxit, Lx=q.Lx, Ly=q.Ly, gx=q.gx, gy=q.gy, rho1=q.rho1,
+                             rho2=q.rho2, m1=q.m1, m2=q.m2, sigma=q.sigma, rro=q.rro, usouth=q.usouth,
+                             unorth=q.unorth, vwest=q.vwest, veast=q.veast, dt=q.dt, dx=q.dx, dy=q.dy,
+                             maxError=q.maxError, beta=q.beta)
+        return st, pr
+
+    def run(self, nsteps: int):
+        """nsteps time steps (the loop code3_fun.jl:354-494) in one C call with one wait at its end; the four
+        sweep counts of every step."""
+        if not self.fused:
+            return [self.step() for _ in range(nsteps)]
+        st, pr = self._c_args()
+        sw = (C.c_int * max(4 * nsteps, 1))()
+        self.ctx.bub_code3_run(C.byref(st), C.byref(pr), nsteps, sw)
+        self.Nf = st.Nf
+        self.time += nsteps * self.q.dt
+        out = [list(sw[4 * k: 4 * k + 4]) for k in range(nsteps)]
+        if out:
+            self.sweeps = out[-1]
+        return out
+
     def step(self):
         """code3_fun.jl:356-494."""
         q, k, nx, ny = self.q, self.ctx, self.q.nx, self.q.ny
         dt, dx, dy = q.dt, q.dx, q.dy
         if self.fused:
-            st = _lib.CCode3State(**{n: getattr(self, n).ptr for n in self.GRID + self.FRONT}, Nf=self.Nf, cap=q.cap)
-            pr = _lib.CBubParams(nx=nx, ny=ny, maxit=q.maxit, Lx=q.Lx, Ly=q.Ly, gx=q.gx, gy=q.gy, rho1=q.rho1,
-                                 rho2=q.rho2, m1=q.m1, m2=q.m2, sigma=q.sigma, rro=q.rro, usouth=q.usouth,
-                                 unorth=q.unorth, vwest=q.vwest, veast=q.veast, dt=dt, dx=dx, dy=dy,
-                                 maxError=q.maxError, beta=q.beta)
+            st, pr = self._c_args()
             sw = (C.c_int * 4)()
             k.bub_code3_step(C.byref(st), C.byref(pr), sw)
             self.Nf = st.Nf

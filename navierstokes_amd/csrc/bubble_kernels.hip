@@ -15,6 +15,7 @@
 // sequential accumulation order without atomics.
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "nsk_internal.h"
 
@@ -1296,7 +1297,7 @@ __device__ __forceinline__ T uniform(const T &v) {
 // regridding's three vectors of Nf+2.
 template <bool FAST>
 __global__ void __launch_bounds__(1024) k_code3_step(nsk_bub_code3_state s_arg, nsk_bub_params q_arg, double *snap, int W, int P,
-                                                     int M, unsigned long long *words, double *change_word) {
+                                                     int M, unsigned long long *words, double *change_word, int *nf_dev) {
   extern __shared__ double lds[];
   __shared__ nsk_bub_code3_state ls;
   __shared__ nsk_bub_params lq;
@@ -1304,9 +1305,14 @@ __global__ void __launch_bounds__(1024) k_code3_step(nsk_bub_code3_state s_arg, 
   if (tid == 0) {
     ls = s_arg;
     lq = q_arg;
+    if (nf_dev) ls.Nf = *nf_dev;  // a run of steps keeps the front size on the device
   }
   __syncthreads();
   auto word = [&](int k) { return reinterpret_cast<int *>(words + k); };  // 8-byte words, an int in each
+  if (uniform(ls.Nf) < 0) {  // an earlier step of the run outgrew the front vectors
+    if (tid == 0) *word(4) = -1;
+    return;
+  }
   {
     // un, vn, rn, mn, xfn, yfn = u, v, r, m, xf, yf (:357-362)
     const nsk_bub_code3_state s = uniform(ls);
@@ -1434,7 +1440,11 @@ __global__ void __launch_bounds__(1024) k_code3_step(nsk_bub_code3_state s_arg, 
   for (int l = 2 + tid; l <= Nf + 1; l += nth)
     s_d[l] = sqrt(SQ((s_x[l - 1] - s_x[l - 2]) / q.dx) + SQ((s_y[l - 1] - s_y[l - 2]) / q.dy));
   __syncthreads();
-  if (tid == 0) *word(4) = regrid_chain<true>(s.xf, s.yf, s_x, s_y, s_d, q.dx, q.dy, Nf, s.cap);
+  if (tid == 0) {
+    const int nn = regrid_chain<true>(s.xf, s.yf, s_x, s_y, s_d, q.dx, q.dy, Nf, s.cap);
+    *word(4) = nn;
+    if (nf_dev) *nf_dev = nn;
+  }
 }
 
 // phases of a launch walk the grid with every thread of the workgroup: as many as there are cells,
@@ -1514,7 +1524,7 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
       NSK_HIP(nsk_allow_lds(ctx, (const void *)kernel, lds_bytes));
       // sweep counts and front size go straight to the pinned host words (device-visible)
       kernel<<<1, merged_threads(plp, nx, ny), lds_bytes, ctx->stream>>>(*s, *q, ctx->sor_snap, plp.W, plp.P, plp.M, ctx->red_host + 8,
-                                                                         reinterpret_cast<double *>(ctx->red_dev + 3));
+                                                                         reinterpret_cast<double *>(ctx->red_dev + 3), nullptr);
       NSK_LAUNCH_CHECK();
       NSK_HIP(hipStreamSynchronize(ctx->stream));
       const int nf_new = host_word(ctx, 4);
@@ -1564,5 +1574,102 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
   s->Nf = nf_new;
   if (sweeps_out)
     for (int k = 0; k < 4; k++) sweeps_out[k] = host_word(ctx, k);
+  return 0;
+}
+
+// ---- time loops ----------------------------------------------------------------------------------
+// The reference's drivers are loops over time steps (DNS.jl:70-102, code3_fun.jl:354-494).  On grids
+// where a time step is one launch, a run of steps is queued back to back: nothing of a step is
+// needed on the host before the next one starts (code3's front size stays on the device), so the
+// host waits once per run instead of once per step.
+namespace {
+// eight words per step of a run: the step's sweep counts and, for code3, the front size after it
+int run_words(nsk_ctx *ctx, int nsteps, unsigned long long **words) {
+  const size_t need = (size_t)nsteps * 8;
+  if (ctx->run_words_cap < need) {
+    if (ctx->run_words) NSK_HIP(hipFree(ctx->run_words));
+    ctx->run_words = nullptr;
+    ctx->run_words_cap = 0;
+    NSK_HIP(hipMalloc(&ctx->run_words, need * sizeof(unsigned long long)));
+    ctx->run_words_cap = need;
+  }
+  *words = ctx->run_words;
+  return 0;
+}
+}  // namespace
+
+extern "C" int nsk_bub_dns_run(nsk_ctx *ctx, const nsk_bub_dns_state *s, const nsk_bub_params *q, int nsteps, int *sweeps_out) {
+  NSK_CTX(ctx);
+  NSK_REQUIRE(s != nullptr && q != nullptr && nsteps >= 0, "nsk_bub_dns_run: bad arguments (nsteps=%d)", nsteps);
+  NSK_NONNULL(s->u, s->v, s->p, s->ut, s->vt, s->tmp1, s->tmp2, s->r, s->ro, s->rt, s->uu, s->vv);
+  const int nx = q->nx, ny = q->ny;
+  NSK_BGRID_OK(nx, ny);
+  const PipePlan pl = pipe_plan(ctx, 0, nx, ny, q->maxit);
+  if (!(ctx->bub_merge_launches && pl.ok && pl.pre) || nsteps == 0) {
+    for (int k = 0; k < nsteps; k++)
+      if (int rc = nsk_bub_dns_step(ctx, s, q, sweeps_out ? sweeps_out + k : nullptr)) return rc;
+    return 0;
+  }
+  unsigned long long *words = nullptr;
+  if (int rc = run_words(ctx, nsteps, &words)) return rc;
+  if (int rc = pipe_reserve(ctx, pl, nx, ny)) return rc;
+  const auto kernel = pl.fast ? k_dns_step<true> : k_dns_step<false>;
+  NSK_HIP(nsk_allow_lds(ctx, (const void *)kernel, pl.pbytes));
+  for (int k = 0; k < nsteps; k++) {
+    kernel<<<1, merged_threads(pl, nx, ny), pl.pbytes, ctx->stream>>>(*s, *q, ctx->sor_snap, pl.W, pl.P, pl.M,
+                                                                      reinterpret_cast<int *>(words + 8 * (size_t)k),
+                                                                      reinterpret_cast<double *>(ctx->red_dev + 3));
+    NSK_LAUNCH_CHECK();
+  }
+  if (sweeps_out) {
+    std::vector<unsigned long long> host((size_t)nsteps * 8);
+    NSK_HIP(hipMemcpyAsync(host.data(), words, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    NSK_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < nsteps; k++) sweeps_out[k] = (int)(unsigned)host[8 * (size_t)k];
+  }
+  return 0;
+}
+
+extern "C" int nsk_bub_code3_run(nsk_ctx *ctx, nsk_bub_code3_state *s, const nsk_bub_params *q, int nsteps, int *sweeps_out) {
+  NSK_CTX(ctx);
+  NSK_REQUIRE(s != nullptr && q != nullptr && nsteps >= 0, "nsk_bub_code3_run: bad arguments (nsteps=%d)", nsteps);
+  NSK_NONNULL(s->u, s->v, s->p, s->ut, s->vt, s->tmp1, s->tmp2, s->fx, s->fy, s->un, s->vn, s->r, s->m, s->rn, s->mn, s->rt);
+  NSK_NONNULL(s->xf, s->yf, s->xfn, s->yfn, s->uf, s->vf, s->tx, s->ty, s->xs, s->ys);
+  const int nx = q->nx, ny = q->ny;
+  NSK_BGRID_OK(nx, ny);
+  NSK_REQUIRE(s->Nf >= 1 && s->cap >= s->Nf + 2, "nsk_bub_code3_run: front of %d points in vectors of %d", s->Nf, s->cap);
+  const PipePlan plp = pipe_plan(ctx, 0, nx, ny, q->maxit), pld = pipe_plan(ctx, 1, nx, ny, q->maxit);
+  size_t lds_bytes = plp.pbytes > pld.pbytes ? plp.pbytes : pld.pbytes;
+  const size_t front_bytes = sizeof(double) * 10 * (size_t)s->cap;
+  if (front_bytes > lds_bytes) lds_bytes = front_bytes;
+  if (!(ctx->bub_merge_launches && plp.ok && plp.pre && pld.ok && lds_bytes <= 156 * 1024) || nsteps == 0) {
+    for (int k = 0; k < nsteps; k++)
+      if (int rc = nsk_bub_code3_step(ctx, s, q, sweeps_out ? sweeps_out + 4 * k : nullptr)) return rc;
+    return 0;
+  }
+  unsigned long long *words = nullptr;
+  if (int rc = run_words(ctx, nsteps, &words)) return rc;
+  if (int rc = pipe_reserve(ctx, plp, nx, ny)) return rc;
+  const auto kernel = plp.fast ? k_code3_step<true> : k_code3_step<false>;
+  NSK_HIP(nsk_allow_lds(ctx, (const void *)kernel, lds_bytes));
+  // the front size travels from step to step in a device word
+  int *nf_dev = reinterpret_cast<int *>(ctx->red_dev + 20);
+  *reinterpret_cast<int *>(ctx->red_host + 20) = s->Nf;
+  NSK_HIP(hipMemcpyAsync(nf_dev, ctx->red_host + 20, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  for (int k = 0; k < nsteps; k++) {
+    kernel<<<1, merged_threads(plp, nx, ny), lds_bytes, ctx->stream>>>(*s, *q, ctx->sor_snap, plp.W, plp.P, plp.M, words + 8 * (size_t)k,
+                                                                       reinterpret_cast<double *>(ctx->red_dev + 3), nf_dev);
+    NSK_LAUNCH_CHECK();
+  }
+  std::vector<unsigned long long> host((size_t)nsteps * 8);
+  NSK_HIP(hipMemcpyAsync(host.data(), words, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  NSK_HIP(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < nsteps; k++) {
+    const int nf = (int)(unsigned)host[8 * (size_t)k + 4];
+    NSK_REQUIRE(nf >= 0, "nsk_bub_code3_run: the front outgrew its capacity of %d points in step %d of the run", s->cap, k + 1);
+    s->Nf = nf;
+    if (sweeps_out)
+      for (int j = 0; j < 4; j++) sweeps_out[4 * k + j] = (int)(unsigned)host[8 * (size_t)k + j];
+  }
   return 0;
 }

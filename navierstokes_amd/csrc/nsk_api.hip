@@ -71,6 +71,7 @@ extern "C" int nsk_destroy(nsk_ctx *c) {
   if (c->stage) (void)hipFree(c->stage);
   if (c->iter_pp) (void)hipFree(c->iter_pp);
   if (c->sor_snap) (void)hipFree(c->sor_snap);
+  if (c->run_words) (void)hipFree(c->run_words);
   if (c->ev_edge) (void)hipEventDestroy(c->ev_edge);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->hist_dev) (void)hipFree(c->hist_dev);

@@ -50,6 +50,8 @@ struct nsk_ctx {
   int sor_pipeline = 1;  // lexicographic SOR: 1 = several sweeps in flight when everything fits LDS, 0 = one at a time
   double *sor_snap = nullptr;  // per-sweep snapshots of the unknown for that kernel
   size_t sor_snap_elems = 0;
+  unsigned long long *run_words = nullptr;  // per-step counters of nsk_bub_dns_run / nsk_bub_code3_run
+  size_t run_words_cap = 0;
   // Largest dynamic LDS size already allowed for a kernel through this context (the attribute call
   // costs microseconds, a time step of the bubble drivers a hundred).
   struct LdsAllowed {

@@ -335,6 +335,40 @@ def test_code3_steps(form, nx, ny, Nf):
     assert same_bits(gx, ox) and same_bits(gy, oy)
 
 
+@pytest.mark.parametrize("merged", [1, 0])
+def test_runs_of_steps(merged):
+    """The time loops in one C call each (nsk_bub_dns_run, nsk_bub_code3_run): the sweep counts of every
+    step, the front sizes and the final fields are those of the oracle's step-by-step loop; a run
+    continues where single steps left off and the other way round."""
+    q = DNSParams()
+    g, o = DNS(q), OracleDNS(q)
+    g.ctx.set_option("bub_merge_launches", merged)
+    try:
+        assert g.run(0) == []
+        assert g.run(13) == [o.step() for _ in range(13)]
+        assert g.step() == o.step()
+        assert g.run(6) == [o.step() for _ in range(6)]
+        for k in ("rho", "u", "v", "p", "uu", "vv"):
+            assert same_bits(getattr(g, k).get(), getattr(o, k)), k
+        assert abs(g.time - 20 * q.dt) < 1e-12
+        q3 = Code3Params()
+        g3, o3 = Code3(q3), OracleCode3(q3)
+        assert g3.run(7) == [o3.step() for _ in range(7)] and g3.Nf == o3.Nf
+        assert g3.step() == o3.step() and g3.Nf == o3.Nf
+        assert g3.run(5) == [o3.step() for _ in range(5)] and g3.Nf == o3.Nf
+        for k in ("r", "m", "u", "v", "p"):
+            assert same_bits(getattr(g3, k).get(), getattr(o3, k)), k
+        (gx, gy), (ox, oy) = g3.front(), o3.front()
+        assert same_bits(gx, ox) and same_bits(gy, oy)
+        # a front that outgrows its vectors in the middle of a run is an error of the run
+        from navierstokes_amd import _lib
+        g4 = Code3(Code3Params(nx=48, ny=48, Nf=40, cap=48))
+        with pytest.raises(_lib.NskError, match="outgrew its capacity"):
+            g4.run(4)
+    finally:
+        g.ctx.set_option("bub_merge_launches", 1)
+
+
 def test_fused_steps_report_their_errors(gpu):
     """Null arrays, a front that does not fit its vectors and a front that outgrows them are errors of
     the whole-step entry points, not faults."""

@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 
+from navierstokes_amd import _lib
 from navierstokes_amd.bubble import Code3, Code3Params, DNS, DNSParams
 from oracle.bubble_oracle import FrontLeftTheBox, OracleCode3, OracleDNS
 from fuzz_poisson import strict_same
@@ -45,9 +46,13 @@ def sweep(cases, seed, verbose=True):
             g, o = DNS(q), OracleDNS(q)
             g.fused = bool(rng.integers(0, 2))
             g.ctx.set_option("bub_merge_launches", int(rng.integers(0, 2)))
-            for _ in range(steps):
-                if g.step() != o.step():
-                    ok, why = False, "sweep count"
+            if g.fused and rng.random() < 0.5:     # the same steps as one run (one C call)
+                if g.run(steps) != [o.step() for _ in range(steps)]:
+                    ok, why = False, "sweep counts of a run"
+            else:
+                for _ in range(steps):
+                    if g.step() != o.step():
+                        ok, why = False, "sweep count"
             for k in ("rho", "u", "v", "p", "uu", "vv"):
                 if ok and not strict_same(getattr(g, k).get(), getattr(o, k)):
                     ok, why = False, k
@@ -60,16 +65,24 @@ def sweep(cases, seed, verbose=True):
             g, o = Code3(q), OracleCode3(q)
             g.fused = bool(rng.integers(0, 2))
             g.ctx.set_option("bub_merge_launches", int(rng.integers(0, 2)))
-            left = False
+            left, as_run, sos = False, g.fused and rng.random() < 0.5, []
             for _ in range(steps):
                 try:
                     so = o.step()
                 except FrontLeftTheBox:      # the run ends there in the reference too
                     left = True
                     break
-                if g.step() != so or g.Nf != o.Nf:
+                if as_run:
+                    sos.append(list(so))
+                elif g.step() != so or g.Nf != o.Nf:
                     ok, why = False, "sweep counts / front size"
                     break
+            if as_run and not left:          # the same steps as one run (one C call)
+                try:
+                    if g.run(steps) != sos or g.Nf != o.Nf:
+                        ok, why = False, "sweep counts / front size of a run"
+                except _lib.NskError as e:
+                    ok, why = False, f"run failed: {e}"
             if left:
                 if verbose:
                     print(f"   case {case}: code3 {nx}x{ny} maxit={q.maxit}: the front left the box, case dropped", flush=True)

@@ -27,3 +27,10 @@ sw, us = run(DNS(DNSParams()), 20, 200)
 print(f"DNS.jl 32x32: {sw:.1f} sweeps per pressure solve = {63 + 2 * (sw - 1):.0f} barrier steps of the pipeline, {us:.1f} us per time step")
 sw, us = run(Code3(Code3Params()), 20, 100)
 print(f"code3 32x32, Nf=100: sweeps per solve (pressure, density, pressure, density) {np.round(sw, 1)}, {us:.1f} us per time step")
+for name, sim, n in (("DNS.jl", DNS(DNSParams()), 200), ("code3", Code3(Code3Params()), 100)):
+    sim.run(20)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    sim.run(n)
+    torch.cuda.synchronize()
+    print(f"{name}: {(time.time() - t0) / n * 1e6:.1f} us per time step as a run of {n} steps in one call")

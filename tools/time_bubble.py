@@ -23,9 +23,20 @@ def rate(sim, n, sync):
     return n / (time.perf_counter() - t0)
 
 
+def run_rate(sim, n):
+    """the same steps as one run (one C call, one wait)"""
+    sim.run(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sim.run(n)
+    torch.cuda.synchronize()
+    return n / (time.perf_counter() - t0)
+
+
 gs = torch.cuda.synchronize
 print(f"DNS.jl   (32x32, SOR to 1e-3): GPU {rate(DNS(DNSParams()), 100, gs):7.1f} steps/s, oracle {rate(OracleDNS(DNSParams()), 100, lambda: None):7.1f} steps/s")
 print(f"code3    (32x32, Nf=100)     : GPU {rate(Code3(Code3Params()), 50, gs):7.1f} steps/s, oracle {rate(OracleCode3(Code3Params()), 50, lambda: None):7.1f} steps/s")
+print(f"as runs of 100 / 50 steps in one call: DNS {run_rate(DNS(DNSParams()), 100):7.1f} steps/s, code3 {run_rate(Code3(Code3Params()), 50):7.1f} steps/s")
 for n in (256, 512):
     q = DNSParams(nx=n, ny=n, dt=0.00125 * (32 / n) ** 2, maxit=200, pressure_solver="redblack")
     print(f"DNS {n}x{n} red/black: GPU {rate(DNS(q), 10, gs):7.1f} steps/s, oracle {rate(OracleDNS(q), 3, lambda: None):7.2f} steps/s")
