@@ -6,6 +6,8 @@ of the back-trace, the multi-pass Poisson kernel on windows with halo edges -- a
 single-domain oracle, bit for bit."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -76,3 +78,19 @@ def test_slab_time_steps_on_gpu(tmp_path, world, halo, schedule, nx, ny_loc):
         assert np.array_equal(got, getattr(ref, k)), k
     got = torch.cat([q["dP"] for q in parts]).numpy().T
     assert np.array_equal(got[1:-1, 1:-1], ref.dPrdtau)
+
+
+def test_rccl_branch_of_every_schedule_to_self():
+    """The torch.distributed/RCCL branch of the three slab schedules as far as one GPU can take it: a
+    one-rank `nccl` process group, every isend/irecv of an interior rank addressed to itself, against
+    the same run with the halo rows refilled by device copies (tools/rccl_self_rehearsal.py).  Runs in
+    a process of its own (the process group is process-wide) under a time limit, so that a stalled
+    collective ends the test instead of the suite."""
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "rccl_self_rehearsal.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-u", tool, "95", "60", "8", "40"], env=env, timeout=100,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    for schedule in ("plain", "edges", "bands"):
+        assert f"{schedule:6s} RCCL-to-self == loopback: True" in r.stdout, r.stdout[-3000:]
+    assert "all-reduce keeps NaN: True" in r.stdout
