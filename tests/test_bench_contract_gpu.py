@@ -45,6 +45,32 @@ def test_single_gpu_line():
     assert t["steps"] == 1 and t["poisson_iters"][0] % 10232 == 0 and t["steps_per_s"] > 0
 
 
+def test_two_rank_line_as_the_driver_launches_it():
+    """N > 1 the way a harness starts it (torch.distributed.run, one rank per process), rehearsed on the
+    one GPU: both ranks share cuda:0 and the halo rows travel through gloo -- the decomposition, the
+    schedule, the max over ranks and the extra keys of the line are the ones of a real node, the rate is
+    not a measurement."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--passes", "150", "--backend", "gloo", "--one-gpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]               # rank 0 only
+    j = json.loads(lines[0])
+    assert (j["n_gpus"], j["steps"], j["warmup"], j["scaling"]) == (2, 2, 1, "weak")
+    assert j["config"]["parallelism"] == "slab2" and j["config"]["halo_rows"] == 60
+    assert j["config"]["grid_per_gpu"] == [2559, 4095] and j["schedule"] == "edges"
+    assert j["exchanges_timed"] == 2 * 3 and j["comm_exposed_us_per_exchange"] > 0      # ceil(150 / 60) per step
+    assert abs(j["value"] - 40.0 * 2559 * 4095 * 2 / (j["t_iter_us"] * 1e-6) / 1e9) < 1e-6 * j["value"]
+    assert "cpu_baseline" not in j and "time_steps" not in j
+
+
 def test_traffic_record_matches_the_build():
     """profiles/poisson_traffic.json is only used when it was measured on the kernel build in the tree."""
     from navierstokes_amd._lib import poisson_kernel_hash
