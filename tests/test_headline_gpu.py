@@ -164,3 +164,85 @@ def test_eight_slabs_of_2559x4095(tmp_path, capsys):
         a, b = max(rows.start, 1), min(rows.stop, nyg - 1)
         assert same_bits(got[1:-1, a - rows.start:b - rows.start], dP[:, a - 1:b - 1]), f"dPrdtau of rank {r}"
         assert np.load(os.path.join(tmp_path, f"res{r}.npy"))[0] == want_res, f"residual on rank {r}"
+
+
+def test_eight_slabs_of_2559x4095_behind_the_c_abi(capsys):
+    """The same grid through nsk_slabs_* the way a single-threaded driver (Julia's ccall) holds a node:
+    one group with all eight slabs, the reference's global arrays scattered by nsk_slabs_upload, halo
+    rows moved by peer copies between the slabs' streams (here all on cuda:0), 30 passes = 3 exchanges
+    with the edges-first schedule, the residual, and the gathered arrays against the single-domain
+    oracle."""
+    from navierstokes_amd import _lib
+    from navierstokes_amd.ns import c_params
+    from oracle.ns_oracle import Oracle
+    nyg = NY_LOC * WORLD
+    p1 = ns_params("NavierStokes_Re6", n=16)
+    p = p1.with_(ny=nyg, ly=p1.ly * WORLD)
+    Pr = np.asfortranarray(global_rows(0, 0, nyg).T)
+    dv = np.asfortranarray(global_rows(2, 0, nyg).T)
+    dP = np.asfortranarray(global_rows(1, 0, nyg).T[1:-1, 1:-1])
+    say(capsys, "8 slabs in one group on cuda:0: upload, 30 passes, residual, download")
+    g = _lib.Slabs(WORLD, 0, [0] * WORLD, c_params(p), NY_LOC, HALO, transport=2)
+    try:
+        for name, a in (("Pr", Pr), ("dPrdtau", dP), ("divV", dv)):
+            g.upload(name, a)
+        g.poisson_iters(PASSES)
+        got_res = g.residual()
+        assert g.info()["exchanges"] == 3
+        got_Pr, got_dP = np.full((NX, nyg), np.nan, order="F"), np.full((NX - 2, nyg - 2), np.nan, order="F")
+        g.download("Pr", got_Pr)
+        g.download("dPrdtau", got_dP)
+    finally:
+        g.close()
+    o = Oracle(omp=True)
+
+    def passes():
+        for _ in range(PASSES):
+            o.update_dPrdtau(Pr, dP, dv, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy)
+            o.update_Pr(Pr, dP, p.dtau)
+            o.set_bc_Pr(Pr, 0.0, False)
+        Rp = np.zeros((NX - 2, nyg - 2), order="F")
+        o.compute_res(Rp, Pr, dv, p.rho, p.dt, p.dx, p.dy)
+        return o.maxabs(Rp)
+    want_res = in_thread_with_progress(capsys, "oracle", passes)
+    assert same_bits(got_Pr, Pr) and same_bits(got_dP, dP)
+    assert got_res == want_res
+
+
+def test_time_steps_on_eight_slabs_behind_the_c_abi(capsys):
+    """nsk_slabs_init_flow + nsk_slabs_step (NavierStokes_Re6.jl:72-100 on windows of all thirteen arrays)
+    at the size of the weak-scaled configuration: two time steps from the script's initial condition
+    with the Poisson loop cut to 120 passes (two residual checks) so that the single-domain oracle
+    on 2559 x 32760 finishes in seconds; pass counts, residual history and every field."""
+    from navierstokes_amd import _lib
+    from navierstokes_amd.ns import c_params, init_vprof
+    from oracle.ns_oracle import OracleSim
+    nyg = NY_LOC * WORLD
+    p1 = ns_params("NavierStokes_Re6", n=16)
+    p = p1.with_(ny=nyg, ly=p1.ly * WORLD, niter=120, nchk=60)
+    say(capsys, "8 slabs in one group on cuda:0: two time steps of 120 passes")
+    g = _lib.Slabs(WORLD, 0, [0] * WORLD, c_params(p), NY_LOC, HALO, transport=2)
+    try:
+        g.init_flow(init_vprof(p))
+        got = [g.step() for _ in range(2)]
+        shapes = {"Pr": (NX, nyg), "Vx": (NX + 1, nyg), "Vy": (NX, nyg + 1), "C": (NX, nyg), "dPrdtau": (NX - 2, nyg - 2)}
+        fields = {}
+        for k, shp in shapes.items():
+            fields[k] = np.full(shp, np.nan, order="F")
+            g.download(k, fields[k])
+    finally:
+        g.close()
+    ref = OracleSim(p, omp=True)
+
+    def steps():
+        out = []
+        for _ in range(2):
+            it = ref.step()
+            out.append((it, list(ref.iter_evo), list(ref.err_evo)))
+        return out
+    want = in_thread_with_progress(capsys, "oracle time steps", steps)
+    assert [(a, list(b), list(c)) for a, b, c in got] == want
+    assert want[-1][0] == 120 and len(want[-1][2]) == 2
+    for k in ("Pr", "Vx", "Vy", "C"):
+        assert same_bits(fields[k], getattr(ref, k)), k
+    assert same_bits(fields["dPrdtau"], ref.dPrdtau)
