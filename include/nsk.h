@@ -57,6 +57,8 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *   "poisson_rows_used"    (read only) rows per task of the last launch
  *   "poisson_edge_percent" task height of the first/last column strip in % of the others (0 = 75)
  *   "poisson_xcd"          1 = task numbering that keeps neighbouring tasks on one XCD (default)
+ *   "poisson_stream"       rows of Pr and dPrdtau requested with the non-temporal cache hint: 1 / 0, -1 = where
+ *                          it pays by the size of the fields against the last-level cache (default)
  *   "poisson_stage"        1 = long runs of passes on dense arrays go through pitched copies (default)
  *   "poisson_div"          -1 = automatic, 0 / 2 / 3 / 4 = ask for IEEE / 2- / 3- / 4-operation
  *                          division; a form the two divisors dx, dy do not qualify for is replaced

@@ -184,7 +184,7 @@ struct DmaGeometry {
   static constexpr int LDS_BYTES = (2 * NST + NSG) * 1024;
 };
 
-template <int K, bool ALIGNED, int DIV, bool EDGE>
+template <int K, bool ALIGNED, int DIV, bool EDGE, bool STREAM = false>
 struct Task {
   static constexpr int HK = (K + 1) & ~1;    // column halo, even so that pairs stay aligned
   static constexpr int WOUT = 128 - 2 * HK;  // columns a strip produces
@@ -272,11 +272,15 @@ struct Task {
   // ---- DMA path ----------------------------------------------------------------------------
   // Request row j: 1 KiB of each field straight into LDS, slot sp of the Pr and dPrdτ rings and
   // slot sg of the ∇V ring (64 lanes x 16 bytes, lane-major).
+  // STREAM: Pr and dPrdτ are requested with the non-temporal hint (cache-policy bit `nt` of the load;
+  // ∇V, which every launch reads again, without).  Values do not depend on it; when it pays is the
+  // host's decision (stream_inputs).
   __device__ __forceinline__ void dma_row(int j, int sp, int sg) {
+    constexpr int AUX = STREAM ? 2 : 0;
     const size_t off = (size_t)j * ld + cc;
     char *base = reinterpret_cast<char *>(lds);
-    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(prs + off), (lds_void_t *)(base + sp * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(dps + off), (lds_void_t *)(base + (NST + sp) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(prs + off), (lds_void_t *)(base + sp * 1024), 16, 0, AUX);
+    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(dps + off), (lds_void_t *)(base + (NST + sp) * 1024), 16, 0, AUX);
     __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(dvs + off), (lds_void_t *)(base + (2 * NST + sg) * 1024), 16, 0, 0);
   }
 
@@ -634,7 +638,7 @@ struct Task {
 static __device__ unsigned long long nsk_trace_buf[NSK_POISSON_TRACE * 4];
 #endif
 
-template <int K, bool ALIGNED, int DIV>
+template <int K, bool ALIGNED, int DIV, bool STREAM = false>
 __global__ void __launch_bounds__(64) NSK_WAVES_ATTR k_poisson(PoissonArgs A) {
   constexpr int LDS_VEC = ALIGNED ? DmaGeometry<K>::LDS_BYTES / 16 : (K + 1) * 64;
   __shared__ double2 shared[LDS_VEC];
@@ -681,10 +685,10 @@ __global__ void __launch_bounds__(64) NSK_WAVES_ATTR k_poisson(PoissonArgs A) {
   // A strip is an edge strip when any of its 128 columns is not an interior column.
   const int cfirst = sx * WOUT - HK, clast = cfirst + 127;
   if (cfirst < 1 || clast > A.nx - 2) {
-    Task<K, ALIGNED, DIV, true> t(A, shared, sx, r0, r1);
+    Task<K, ALIGNED, DIV, true, STREAM> t(A, shared, sx, r0, r1);
     t.run_task();
   } else {
-    Task<K, ALIGNED, DIV, false> t(A, shared, sx, r0, r1);
+    Task<K, ALIGNED, DIV, false, STREAM> t(A, shared, sx, r0, r1);
     t.run_task();
   }
 #ifdef NSK_POISSON_TRACE
@@ -796,6 +800,18 @@ inline TaskPlan choose_plan(int nx, int ny, int num_simds, bool staged, int k_fo
   return best;
 }
 
+// Should a launch on an nx x ny window request Pr and dPrdτ with the non-temporal hint?  Measured on
+// MI355X (256 MB last-level cache) over grids of 159 x 255 .. 3839 x 6143, five fields of 8 nx ny
+// bytes per launch: 3-5 % faster where the five fields take 1.4-2 times the cache (2399 x 3839 ..
+// 2879 x 4607: what the previous launch wrote is partly still there, and input rows that are not
+// kept leave it there), even at 1.2 and 2.4 times, 2-4 % slower on grids the cache holds
+// (they are served from it either way, the hint only shortens their stay) and 6 % slower at 3.5
+// times, where the halo rows a neighbouring task reads again are then fetched from memory again.
+inline bool stream_inputs(int nx, int ny) {
+  const double bytes = 5.0 * 8.0 * nx * ny, llc = 256.0 * 1024 * 1024;
+  return bytes >= 1.3 * llc && bytes <= 2.3 * llc;
+}
+
 // `plan` cuts the rows [A.row_begin, A.row_end) (plan_tasks was given their number).
 template <int K>
 int launch_k(nsk_ctx *ctx, hipStream_t stream, PoissonArgs &A, bool aligned, int div, const TaskPlan &plan) {
@@ -810,7 +826,11 @@ int launch_k(nsk_ctx *ctx, hipStream_t stream, PoissonArgs &A, bool aligned, int
   A.xcd_bands = ctx->poisson_xcd;
   const unsigned tasks = (unsigned)plan.tasks;
 #define NSK_LAUNCH(AL, DV) k_poisson<K, AL, DV><<<tasks, 64, 0, stream>>>(A)
-  if (aligned) {
+  // the hint is built for the form every shipped grid takes; the other forms do without
+  const bool hint = ctx->poisson_stream < 0 ? stream_inputs(A.nx, A.ny) : ctx->poisson_stream != 0;
+  if (aligned && div == DIV_FMA2 && hint) {
+    k_poisson<K, true, DIV_FMA2, true><<<tasks, 64, 0, stream>>>(A);
+  } else if (aligned) {
     if (div == DIV_FMA2) NSK_LAUNCH(true, DIV_FMA2);
     else if (div == DIV_FMA3) NSK_LAUNCH(true, DIV_FMA3);
     else if (div == DIV_FMA4) NSK_LAUNCH(true, DIV_FMA4);

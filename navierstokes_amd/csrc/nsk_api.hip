@@ -108,6 +108,11 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
     ctx->poisson_xcd = value != 0;
     return 0;
   }
+  if (!strcmp(name, "poisson_stream")) {
+    NSK_REQUIRE(value >= -1 && value <= 1, "poisson_stream must be -1 (by size), 0 or 1, got %d", value);
+    ctx->poisson_stream = value;
+    return 0;
+  }
   if (!strcmp(name, "poisson_stage")) {
     ctx->poisson_stage = value != 0;
     return 0;
@@ -189,6 +194,10 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   }
   if (!strcmp(name, "poisson_xcd")) {
     *value = ctx->poisson_xcd;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_stream")) {
+    *value = ctx->poisson_stream;
     return 0;
   }
   if (!strcmp(name, "poisson_edge_percent")) {

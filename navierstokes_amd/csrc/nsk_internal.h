@@ -42,6 +42,7 @@ struct nsk_ctx {
   int last_div = -1;     // form the last fused Poisson call used (nsk_get_option "poisson_div_used")
   int poisson_edge_percent = 0;  // rows per task of the edge strips in % of poisson_rows, 0 = default
   int poisson_xcd = 1;   // XCD-aware task numbering of the Poisson kernel (0 = plain)
+  int poisson_stream = -1;  // non-temporal requests for Pr and dPrdtau rows: -1 = by the size of the fields, 0 / 1
   int edge_task_rows = 0;  // task height of the edge rows in nsk_ns_poisson_iters_edges_first, 0 = default
   // nsk_ns_poisson_iters_edges_first (created on first use): fork and edge-rows-final events
   hipEvent_t ev_fork = nullptr, ev_edge = nullptr;

@@ -218,16 +218,21 @@ def test_poisson_full_size_grid(oracle):
     oracle_iters(oracle, p, Pr, dP, dv, 11, 0)
     ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
     try:
-        for k, rows, edge, xcd in [(0, 0, 0, 1), (0, 0, 0, 0), (3, 37, 50, 1), (8, 200, 100, 1), (1, 0, 0, 1)]:
+        # (passes per launch, rows per task, edge-strip height %, XCD numbering, non-temporal row requests)
+        for k, rows, edge, xcd, stream in [(0, 0, 0, 1, -1), (0, 0, 0, 0, 0), (0, 0, 0, 1, 1), (3, 37, 50, 1, 1),
+                                           (8, 200, 100, 1, -1), (1, 0, 0, 1, 0)]:
             ctx.set_option("poisson_k", k)
             ctx.set_option("poisson_rows", rows)
             ctx.set_option("poisson_edge_percent", edge)
             ctx.set_option("poisson_xcd", xcd)
+            ctx.set_option("poisson_stream", stream)
+            assert ctx.get_option("poisson_stream") == stream
             gPr, gdP = run_gpu(ctx, p, Pr0, dP0, dv, 11, 0, True)
-            assert same_bits(gPr, Pr), (k, rows, edge, xcd, np.argwhere(gPr != Pr)[:5])
-            assert same_bits(gdP, dP), (k, rows, edge, xcd, np.argwhere(gdP != dP)[:5])
+            assert same_bits(gPr, Pr), (k, rows, edge, xcd, stream, np.argwhere(gPr != Pr)[:5])
+            assert same_bits(gdP, dP), (k, rows, edge, xcd, stream, np.argwhere(gdP != dP)[:5])
         ctx.set_option("poisson_k", 0)
         ctx.set_option("poisson_rows", 0)
+        ctx.set_option("poisson_stream", -1)
         gPr, gdP = run_gpu(ctx, p, Pr0, dP0, dv, 11, 0, False)      # dense, odd leading dimension
         assert same_bits(gPr, Pr) and same_bits(gdP, dP)
     finally:

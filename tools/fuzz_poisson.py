@@ -61,6 +61,7 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
         rows = int(rng.choice([0, 0, 2, 3, 5, 8, 13, 24, 48, 100]))
         edge = int(rng.choice([0, 0, 25, 50, 100]))
         xcd = int(rng.integers(0, 2))
+        stream = int(rng.integers(-1, 2))
         full = int(rng.integers(0, 2))
         count = int(rng.integers(1, 3 * max(K, 3) + 2))
         scale, zero_frac = [(1.0, 0.0), (1.0, 0.0), (1e-2, 0.0), (1.0, 0.5), (1e-200, 0.0), (1e-300, 0.2), (1e-310, 0.3),
@@ -92,7 +93,8 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
         wPr, wdv = np.asfortranarray(Pr0[:, lo:hi]), np.asfortranarray(dv[:, lo:hi])
         wdP = np.asfortranarray(dP0[:, lo:hi - 2])
         nyw = hi - lo
-        for opt, v in (("poisson_k", K), ("poisson_rows", rows), ("poisson_edge_percent", edge), ("poisson_xcd", xcd)):
+        for opt, v in (("poisson_k", K), ("poisson_rows", rows), ("poisson_edge_percent", edge), ("poisson_xcd", xcd),
+                       ("poisson_stream", stream)):
             ctx.set_option(opt, v)
         if pitched:
             ld = _pitch(nx)
@@ -136,7 +138,7 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
         if hi < nyg and sk_hi == 0:
             ok = ok and strict_same(gPr[:, -1], wPr[:, -1])
         desc = (f"case {case}: nx={nx} nyg={nyg} window=[{lo},{hi}) pitched={pitched} K={K}->{ctx.get_option('poisson_k')} rows={rows} "
-                f"edge={edge} xcd={xcd} full={full} count={count} scale={scale} zeros={zero_frac} div={ctx.get_option('poisson_div_used')} "
+                f"edge={edge} xcd={xcd} stream={stream} full={full} count={count} scale={scale} zeros={zero_frac} div={ctx.get_option('poisson_div_used')} "
                 f"edges_first={ef}")
         if not ok:
             bad += 1
@@ -147,6 +149,7 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
     for opt in ("poisson_k", "poisson_rows", "poisson_edge_percent", "poisson_edge_task_rows"):
         ctx.set_option(opt, 0)
     ctx.set_option("poisson_xcd", 1)
+    ctx.set_option("poisson_stream", -1)
     if verbose:
         print(f"{a.cases} cases, {bad} mismatches, {time.time() - t_start:.0f} s")
     return failures
