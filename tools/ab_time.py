@@ -15,12 +15,14 @@ lib = C.CDLL(sys.argv[1])
 launches = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 p = ns_params("NavierStokes_Re6", n=int(os.environ.get("AB_N", "16")))
 K = int(os.environ.get("AB_K", "6"))
-nx, ny, ld = p.nx, p.ny, _pitch(p.nx)
+nx, ny, ld = p.nx, p.ny, int(os.environ.get("AB_LD", "0")) or _pitch(p.nx)   # AB_LD = row pitch in doubles
 torch.cuda.set_device(0)
 h = C.c_void_p()
 assert lib.nsk_create(0, C.byref(h)) == 0
 assert lib.nsk_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
 assert lib.nsk_set_option(h, b"poisson_k", K) == 0
+ROWS = int(os.environ.get("AB_ROWS", "0"))
+assert lib.nsk_set_option(h, b"poisson_rows", ROWS) == 0
 g = torch.Generator(device="cpu").manual_seed(1)
 def rnd():
     t = torch.zeros((ny, ld), dtype=torch.float64)
@@ -38,4 +40,4 @@ e0.record()
 assert run(6 * launches) == 0
 e1.record()
 torch.cuda.synchronize()
-print(f"{os.path.basename(sys.argv[1])} {nx}x{ny} K={K or 'auto'}: {e0.elapsed_time(e1) * 1e3 / (6 * launches):.2f} us/pass")
+print(f"{os.path.basename(sys.argv[1])} {nx}x{ny} K={K or 'auto'} rows={ROWS or 'auto'} ld={ld}: {e0.elapsed_time(e1) * 1e3 / (6 * launches):.2f} us/pass")
