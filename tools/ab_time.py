@@ -22,6 +22,9 @@ assert lib.nsk_create(0, C.byref(h)) == 0
 assert lib.nsk_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
 assert lib.nsk_set_option(h, b"poisson_k", K) == 0
 ROWS = int(os.environ.get("AB_ROWS", "0"))
+for opt in os.environ.get("AB_OPTS", "").split():        # AB_OPTS="name=value ..." (options this build has)
+    name, v = opt.split("=")
+    assert lib.nsk_set_option(h, name.encode(), int(v)) == 0, opt
 assert lib.nsk_set_option(h, b"poisson_rows", ROWS) == 0
 g = torch.Generator(device="cpu").manual_seed(1)
 def rnd():
@@ -40,4 +43,4 @@ e0.record()
 assert run(6 * launches) == 0
 e1.record()
 torch.cuda.synchronize()
-print(f"{os.path.basename(sys.argv[1])} {nx}x{ny} K={K or 'auto'} rows={ROWS or 'auto'} ld={ld}: {e0.elapsed_time(e1) * 1e3 / (6 * launches):.2f} us/pass")
+print(f"{os.path.basename(sys.argv[1])} {nx}x{ny} K={K or 'auto'} rows={ROWS or 'auto'} ld={ld} {os.environ.get('AB_OPTS', '')}: {e0.elapsed_time(e1) * 1e3 / (6 * launches):.2f} us/pass")
