@@ -104,11 +104,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--one-gpu", action="store_true",
                     help="rehearsal: all ranks share cuda:0 (needs --backend gloo; not a measurement)")
-    ap.add_argument("--overlap", action="store_true", help="N>1: same as --schedule bands")
-    ap.add_argument("--schedule", choices=["plain", "edges", "bands"], default=None,
+    ap.add_argument("--schedule", choices=["plain", "edges"], default=None,
                     help="N>1: plain = passes, then the exchange; edges (default) = the rows to be sent come first in "
-                         "the last launch of a block and travel beside the rest of it; bands = boundary bands ahead of "
-                         "the window")
+                         "the last launch of a block and travel beside the rest of it")
     ap.add_argument("--abi-slabs", action="store_true",
                     help="run the slabs through the C ABI (nsk_slabs_*: RCCL called from the library, one slab "
                          "per process) instead of the torch.distributed host path")
@@ -157,7 +155,7 @@ def main():
     dP = torch.zeros((slab.ny_win, ld), dtype=torch.float64, device=dev)
     exchange_rows((Pr, divV), slab)
     be = HipBackend(ctx, p, ld)
-    sp = SlabPoisson(p, slab, be, Pr, dP, divV, schedule="bands" if a.overlap else a.schedule)
+    sp = SlabPoisson(p, slab, be, Pr, dP, divV, schedule=a.schedule)
 
     group = None
     if a.abi_slabs:

@@ -44,6 +44,16 @@ int nsk_create(int device, nsk_ctx **out);
 int nsk_destroy(nsk_ctx *ctx);
 const char *nsk_last_error(void);
 const char *nsk_version(void);
+/* Return values other than 0.  The first two are what every entry point may return; the last two
+ * belong to the code3 time steps (nsk_bub_code3_step / nsk_bub_code3_run). */
+#define NSK_ERR_HIP 1            /* a HIP runtime call failed */
+#define NSK_ERR_ARGUMENT 2       /* an argument or a size is not usable */
+#define NSK_ERR_FRONT_CAPACITY 3 /* the regridded front needs more than `cap` points: the place where
+                                  * scripts/code3_fun.jl:462-465 resizes its vectors; see
+                                  * nsk_bub_code3_run_status for how a caller continues */
+#define NSK_ERR_FRONT_OUTSIDE 4  /* a front point left the box [0,Lx] x [0,Ly]: the reference prints a
+                                  * message (scripts/code3_fun.jl:186-188) and its next array access
+                                  * by that point throws; the state is not to be used */
 /* Use an existing hipStream_t (e.g. the host framework's current stream)
  * instead of the context's own; NULL is HIP's default stream. */
 int nsk_set_stream(nsk_ctx *ctx, void *hip_stream);
@@ -416,7 +426,8 @@ int nsk_bub_update_visco(nsk_ctx *ctx, const double *r, double *m, double m1, do
 /* a = 0.5*(a + b)  code3_fun.jl:445-450 */
 int nsk_bub_average(nsk_ctx *ctx, double *a, const double *b, size_t count);
 /* front regridding  code3_fun.jl:455-494; xf, yf and the two scratch vectors hold `cap`
- * points; an error is returned where the reference would resize its vectors. Synchronous. */
+ * points; NSK_ERR_FRONT_CAPACITY is returned where the reference would resize its vectors (the
+ * front as it was on entry is then in the scratch vectors, Nf + 2 points).  Synchronous. */
 int nsk_bub_regrid_front(nsk_ctx *ctx, double *xf, double *yf, double *xscratch,
                          double *yscratch, double dx, double dy, int Nf, int cap,
                          int *Nf_out);
@@ -461,6 +472,15 @@ int nsk_bub_dns_run(nsk_ctx *ctx, const nsk_bub_dns_state *s, const nsk_bub_para
                     int *sweeps_out);
 int nsk_bub_code3_run(nsk_ctx *ctx, nsk_bub_code3_state *s, const nsk_bub_params *q, int nsteps,
                       int *sweeps_out);
+/* After nsk_bub_code3_step / nsk_bub_code3_run on this context: *steps_done = time steps of that call
+ * that are complete.  When the call returned NSK_ERR_FRONT_CAPACITY, step number *steps_done + 1 is
+ * complete except for its regridding (scripts/code3_fun.jl:455-494): s->Nf is still the size of the
+ * front before it, its averaged front of s->Nf + 2 points is in xs, ys, its four sweep counts are in
+ * sweeps_out, and nothing after it has run.  A caller continues the way the reference's resize! does:
+ * larger front vectors (all ten; only xs, ys carry data), the averaged front copied into the new
+ * xf, yf, nsk_bub_regrid_front on them, then the remaining steps.  No counterpart in the reference
+ * (its vectors grow in place). */
+int nsk_bub_code3_run_status(nsk_ctx *ctx, int *steps_done);
 
 #ifdef __cplusplus
 }

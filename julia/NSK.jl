@@ -9,7 +9,14 @@ struct Ctx
     h::Ptr{Cvoid}
 end
 
-check(rc) = rc == 0 || error(unsafe_string(ccall((:nsk_last_error, lib), Cstring, ())))
+"A nonzero return of the library; code is one of the NSK_ERR_* values of include/nsk.h."
+struct NskError <: Exception
+    code::Cint
+    msg::String
+end
+const ERR_FRONT_CAPACITY = Cint(3)
+const ERR_FRONT_OUTSIDE = Cint(4)
+check(rc) = rc == 0 || throw(NskError(rc, unsafe_string(ccall((:nsk_last_error, lib), Cstring, ()))))
 
 function Ctx(device::Integer=0)
     r = Ref{Ptr{Cvoid}}(C_NULL)
@@ -296,6 +303,12 @@ function code3_run!(c, s::Code3State, q::BubParams, nsteps::Integer)
     sw = zeros(Cint, 4, nsteps)
     check(ccall((:nsk_bub_code3_run, lib), Cint, (Ptr{Cvoid}, Ref{Code3State}, Ref{BubParams}, Cint, Ptr{Cint}), c.h, r, q, nsteps, sw))
     r[], sw
+end
+"Complete time steps of the last code3_step! / code3_run! call on this context (after ERR_FRONT_CAPACITY: the next one lacks only its regridding)."
+function code3_run_status(c)
+    n = Ref{Cint}(0)
+    check(ccall((:nsk_bub_code3_run_status, lib), Cint, (Ptr{Cvoid}, Ptr{Cint}), c.h, n))
+    Int(n[])
 end
 
 # ---- bubble / drop solvers: scripts/DNS.jl (in the form scripts/code1.m states) and ----------

@@ -1,7 +1,8 @@
 # scripts/code3_fun.jl on libnsk: the script body :296-516 (parameters :296-309, front :340-351,
 # time loop :354-494) with every kernel call replaced by one call into the library.  NOT RUN here
-# (no Julia in the build image).  The front vectors are device arrays of fixed capacity `cap`
-# (the reference resizes its host vectors on demand, :462-465).
+# (no Julia in the build image).  The front vectors are device arrays of capacity `cap`; where the
+# reference resizes its host vectors (:462-465) the library returns ERR_FRONT_CAPACITY with the front as
+# it was before the regridding in xs, ys, and the driver regrids again on vectors twice as long.
 include("NSK.jl")
 using .NSK, Printf
 
@@ -45,7 +46,25 @@ function code3(; nstep=300, cap=1024)
         end
         for (a, b) in ((u,un), (v,vn), (r,rn), (m,mn)); NSK.average!(c, a, b, a.n1*a.n2); end            # :445-450
         NSK.average!(c, xf, xfn, Nf+2); NSK.average!(c, yf, yfn, Nf+2)
-        Nf = NSK.regrid_front!(c, xf, yf, xs, ys, dx, dy, Nf, cap)                                       # :455-494
+        Nf = try                                                                                         # :455-494
+            NSK.regrid_front!(c, xf, yf, xs, ys, dx, dy, Nf, cap)
+        catch e
+            (e isa NSK.NskError && e.code == NSK.ERR_FRONT_CAPACITY) || rethrow()
+            xo = NSK.download(c, xs); yo = NSK.download(c, ys)              # the front before the regridding
+            nn = -1
+            while nn < 0                                                     # resize!, :462-465
+                cap *= 2
+                xf, yf, xfn, yfn, uf, vf, tx, ty, xs, ys = (NSK.vec(c, cap) for _ = 1:10)
+                x0 = zeros(cap, 1); y0 = zeros(cap, 1); x0[1:Nf+2] = xo[1:Nf+2]; y0[1:Nf+2] = yo[1:Nf+2]
+                NSK.upload!(c, xf, x0); NSK.upload!(c, yf, y0)
+                try
+                    nn = NSK.regrid_front!(c, xf, yf, xs, ys, dx, dy, Nf, cap)
+                catch e2
+                    (e2 isa NSK.NskError && e2.code == NSK.ERR_FRONT_CAPACITY) || rethrow()
+                end
+            end
+            nn
+        end
         time += dt
         @printf("step %d  time %.5f  front points %d\n", is, time, Nf)
     end

@@ -16,7 +16,14 @@ c_int_p = C.POINTER(C.c_int)
 
 
 class NskError(RuntimeError):
-    pass
+    """A nonzero return of the library; `code` is the NSK_ERR_* value of include/nsk.h."""
+
+    def __init__(self, message: str, code: int = 0):
+        super().__init__(message)
+        self.code = code
+
+
+ERR_HIP, ERR_ARGUMENT, ERR_FRONT_CAPACITY, ERR_FRONT_OUTSIDE = 1, 2, 3, 4
 
 
 class CNSParams(C.Structure):
@@ -113,6 +120,7 @@ _SIGS = {
     "nsk_bub_code3_step": [C.POINTER(CCode3State), C.POINTER(CBubParams), C.POINTER(C.c_int)],
     "nsk_bub_dns_run": [C.POINTER(CDnsState), C.POINTER(CBubParams), _I, C.POINTER(C.c_int)],
     "nsk_bub_code3_run": [C.POINTER(CCode3State), C.POINTER(CBubParams), _I, C.POINTER(C.c_int)],
+    "nsk_bub_code3_run_status": [c_int_p],
     "nsk_ns_poisson_iters_static": [_P, _P, _P, C.POINTER(CNSParams), _I],
     "nsk_ns_poisson_iters_edges_first": [_P, _P, _P, C.POINTER(CNSParams), _I, _I, _I, _I, _I, _P],
     "nsk_ns_residual": [_P, _P, _P, C.POINTER(CNSParams), _I, _I, c_double_p],
@@ -330,7 +338,7 @@ class Context:
     def call(self, name: str, *args) -> None:
         rc = getattr(self.lib, name)(self.handle, *args)
         if rc != 0:
-            raise NskError(f"{name}: {self.lib.nsk_last_error().decode()}")
+            raise NskError(f"{name}: {self.lib.nsk_last_error().decode()}", rc)
 
     def __getattr__(self, name):
         if name.startswith("_") or name in ("set_option", "get_option") or ("nsk_" + name) not in _SIGS:

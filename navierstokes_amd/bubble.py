@@ -237,7 +237,7 @@ class Code3Params:
     maxError: float = 0.001
     beta: float = 1.2
     Nf: int = 100
-    cap: int = 1024         # capacity of the front vectors (the reference resizes on demand)
+    cap: int = 1024         # first capacity of the front vectors; they grow on demand as the reference's do
 
     @property
     def rro(self):
@@ -281,40 +281,84 @@ class Code3:
             setattr(self, k, DArr(*shp.get(k, (nx + 2, ny + 2)), d))
         self.r.t.fill_(q.rho1)       # code3_fun.jl:332-333
         self.m.t.fill_(q.m1)
+        self.cap = q.cap
         for k in self.FRONT:
-            setattr(self, k, DArr(q.cap, 1, d))
+            setattr(self, k, DArr(self.cap, 1, d))
         xf, yf = front_circle(q)
-        pad = np.zeros(q.cap)
+        pad = np.zeros(self.cap)
         pad[: q.Nf + 2] = xf
         self.xf.set(pad)
-        pad = np.zeros(q.cap)
+        pad = np.zeros(self.cap)
         pad[: q.Nf + 2] = yf
         self.yf.set(pad)
         self.Nf = q.Nf
+        self.grown = 0               # times the front vectors were enlarged
         self.time = 0.0
         self.sweeps = [0, 0, 0, 0]
         self.fused = True            # one C call per time step (nsk_bub_code3_step) / one per kernel
 
     def _c_args(self):
         q = self.q
-        st = _lib.CCode3State(**{n: getattr(self, n).ptr for n in self.GRID + self.FRONT}, Nf=self.Nf, cap=q.cap)
+        st = _lib.CCode3State(**{n: getattr(self, n).ptr for n in self.GRID + self.FRONT}, Nf=self.Nf, cap=self.cap)
         pr = _lib.CBubParams(nx=q.nx, ny=q.ny, maxit=q.maxit, Lx=q.Lx, Ly=q.Ly, gx=q.gx, gy=q.gy, rho1=q.rho1,
                              rho2=q.rho2, m1=q.m1, m2=q.m2, sigma=q.sigma, rro=q.rro, usouth=q.usouth,
                              unorth=q.unorth, vwest=q.vwest, veast=q.veast, dt=q.dt, dx=q.dx, dy=q.dy,
                              maxError=q.maxError, beta=q.beta)
         return st, pr
 
+    def _grow_and_regrid(self) -> None:
+        """The place where the reference resizes xf, yf while it regrids (code3_fun.jl:462-465): the step
+        that reported NSK_ERR_FRONT_CAPACITY is complete except for its regridding and left its averaged
+        front (Nf + 2 points) in xs, ys.  Every front vector gets twice the room, the averaged front
+        goes back into xf, yf and the regridding runs again (until it fits)."""
+        n = self.Nf + 2
+        x_old, y_old = self.xs.t[0, :n].clone(), self.ys.t[0, :n].clone()
+        while True:
+            self.cap *= 2
+            self.grown += 1
+            for k in self.FRONT:
+                setattr(self, k, DArr(self.cap, 1, self.dev))
+            self.xf.t[0, :n] = x_old
+            self.yf.t[0, :n] = y_old
+            nf = C.c_int(0)
+            try:
+                self.ctx.bub_regrid_front(self.xf.ptr, self.yf.ptr, self.xs.ptr, self.ys.ptr, self.q.dx, self.q.dy,
+                                          self.Nf, self.cap, C.byref(nf))
+            except _lib.NskError as e:
+                if e.code != _lib.ERR_FRONT_CAPACITY:
+                    raise
+                continue
+            self.Nf = nf.value
+            return
+
+    def _steps_done(self) -> int:
+        n = C.c_int(0)
+        self.ctx.bub_code3_run_status(C.byref(n))
+        return n.value
+
     def run(self, nsteps: int):
         """nsteps time steps (the loop code3_fun.jl:354-494) in one C call with one wait at its end; the four
-        sweep counts of every step."""
+        sweep counts of every step.  A front that outgrows its vectors is given larger ones and the run
+        goes on from the step that needed them."""
         if not self.fused:
             return [self.step() for _ in range(nsteps)]
-        st, pr = self._c_args()
-        sw = (C.c_int * max(4 * nsteps, 1))()
-        self.ctx.bub_code3_run(C.byref(st), C.byref(pr), nsteps, sw)
-        self.Nf = st.Nf
-        self.time += nsteps * self.q.dt
-        out = [list(sw[4 * k: 4 * k + 4]) for k in range(nsteps)]
+        out = []
+        while len(out) < nsteps:
+            left = nsteps - len(out)
+            st, pr = self._c_args()
+            sw = (C.c_int * max(4 * left, 1))()
+            try:
+                self.ctx.bub_code3_run(C.byref(st), C.byref(pr), left, sw)
+                done = left
+                self.Nf = st.Nf
+            except _lib.NskError as e:
+                if e.code != _lib.ERR_FRONT_CAPACITY:
+                    raise
+                done = self._steps_done() + 1      # the step that needed the room counts: only its regridding is left
+                self.Nf = st.Nf
+                self._grow_and_regrid()
+            out += [list(sw[4 * k: 4 * k + 4]) for k in range(done)]
+            self.time += done * self.q.dt
         if out:
             self.sweeps = out[-1]
         return out
@@ -326,8 +370,13 @@ class Code3:
         if self.fused:
             st, pr = self._c_args()
             sw = (C.c_int * 4)()
-            k.bub_code3_step(C.byref(st), C.byref(pr), sw)
-            self.Nf = st.Nf
+            try:
+                k.bub_code3_step(C.byref(st), C.byref(pr), sw)
+                self.Nf = st.Nf
+            except _lib.NskError as e:
+                if e.code != _lib.ERR_FRONT_CAPACITY:
+                    raise
+                self._grow_and_regrid()
             self.time += dt
             self.sweeps = list(sw)
             return self.sweeps
@@ -348,8 +397,15 @@ class Code3:
             k.bub_solve_pressure(self.p.ptr, self.tmp1.ptr, self.tmp2.ptr, self.rt.ptr, q.beta, dx, dy, nx, ny,
                                  q.maxit, q.maxError, C.byref(a), None)
             k.bub_correct_vel(self.u.ptr, self.v.ptr, self.ut.ptr, self.vt.ptr, self.p.ptr, self.r.ptr, dt, dx, dy, nx, ny)
+            out = C.c_int(0)
             k.bub_advect_move_front(self.uf.ptr, self.vf.ptr, self.xf.ptr, self.yf.ptr, self.u.ptr, self.v.ptr,
-                                    dx, dy, dt, q.Lx, q.Ly, nx, ny, self.Nf, None)
+                                    dx, dy, dt, q.Lx, q.Ly, nx, ny, self.Nf, C.byref(out))
+            # where the reference prints "Front out of bounds" (code3_fun.jl:186-188) its next access by
+            # that point throws; a NaN position fails the printed test but throws all the same
+            if out.value or not bool(torch.isfinite(self.xf.t[0, : self.Nf + 2]).all()
+                                     and torch.isfinite(self.yf.t[0, : self.Nf + 2]).all()):
+                raise _lib.NskError(f"a front point left the box [0,{q.Lx}] x [0,{q.Ly}]; the state is not to be used",
+                                    _lib.ERR_FRONT_OUTSIDE)
             k.bub_distribute(self.fx.ptr, self.fy.ptr, self.xf.ptr, self.yf.ptr, q.rho1, q.rho2, dx, dy, nx, ny, self.Nf)
             b = C.c_int(0)
             k.bub_construct_den(self.r.ptr, self.fx.ptr, self.fy.ptr, q.beta, q.maxit, q.maxError, dx, dy, nx, ny, C.byref(b))
@@ -362,8 +418,13 @@ class Code3:
         k.bub_average(self.xf.ptr, self.xfn.ptr, self.Nf + 2)
         k.bub_average(self.yf.ptr, self.yfn.ptr, self.Nf + 2)
         nf = C.c_int(0)
-        k.bub_regrid_front(self.xf.ptr, self.yf.ptr, self.xs.ptr, self.ys.ptr, dx, dy, self.Nf, q.cap, C.byref(nf))
-        self.Nf = nf.value
+        try:
+            k.bub_regrid_front(self.xf.ptr, self.yf.ptr, self.xs.ptr, self.ys.ptr, dx, dy, self.Nf, self.cap, C.byref(nf))
+            self.Nf = nf.value
+        except _lib.NskError as e:
+            if e.code != _lib.ERR_FRONT_CAPACITY:
+                raise
+            self._grow_and_regrid()
         self.time += dt
         self.sweeps = sw
         return sw

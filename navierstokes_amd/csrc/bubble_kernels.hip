@@ -391,8 +391,15 @@ __device__ __forceinline__ double fast_div(double x, double d, double r) {
   return __builtin_fma(-t1, r, q1);
 }
 
+// Debug builds only (tools/debug_sor_call.sh): NSK_SOR_NOINLINE makes the solver a real call from the
+// merged-step kernels, NSK_SOR_DEBUG prints every judged sweep.
+#ifdef NSK_SOR_NOINLINE
+#define NSK_SOR_INLINE __noinline__
+#else
+#define NSK_SOR_INLINE __forceinline__
+#endif
 template <int MODE, bool PRE, bool FAST = false>
-__device__ __forceinline__ void sor_pipe(const SorArgs &A, double *snap, int W, int P, int M) {
+__device__ NSK_SOR_INLINE void sor_pipe(const SorArgs &A, double *snap, int W, int P, int M) {
   static_assert(!FAST || (MODE == 0 && PRE), "the fast division belongs to the pressure solve with face arrays");
   extern __shared__ double lds[];
   const int nx = A.nx, ny = A.ny, ld = nx + 2;
@@ -513,6 +520,9 @@ __device__ __forceinline__ void sor_pipe(const SorArgs &A, double *snap, int W, 
           if (idx == R) idx = 0;
           last = sweep_max[idx];
           const double ch = __longlong_as_double((long long)last);
+#ifdef NSK_SOR_DEBUG
+          if (tid == 0) printf("SOR judge mode=%d fast=%d t=%lld kc=%d idx=%d last=%016llx lds=%u W=%d P=%d M=%d maxit=%d\n", MODE, (int)fast, t, kc, idx, last, (unsigned)(size_t)lds, W, P, M, A.maxit);
+#endif
           if (ch < A.maxError || kc == A.maxit) {  // (false for NaN: keeps sweeping, as the reference does)
             final_sweep = kc;
             break;
@@ -749,7 +759,7 @@ __device__ __forceinline__ void spread_tiles(double *lds, int cap, dp fx, dp fy,
 // then thread 0 of the last block closes the periodic ghost points.
 __device__ __forceinline__ void c_advect_move_front(int l, dp uf, dp vf, dp xf, dp yf, cdp u, cdp v, double dx, double dy,
                                     double dt, double Lx, double Ly, int nx, int ny, int Nf,
-                                    int *out_count) {
+                                    int *out_count, bool nan_is_outside = false) {
   if (l > Nf + 1) return;
   const double xl = xf[l - 1], yl = yf[l - 1];
   // A front point outside the box is an error in the reference (BoundsError); the index clamps
@@ -777,10 +787,14 @@ __device__ __forceinline__ void c_advect_move_front(int l, dp uf, dp vf, dp xf, 
   const double xn = xl + dt * ufl, yn = yl + dt * vfl;
   xf[l - 1] = xn;
   yf[l - 1] = yn;
-  if (out_count && (xn < 0.0 || xn > Lx || yn < 0.0 || yn > Ly)) atomicAdd(out_count, 1);
+  // the reference's message (code3_fun.jl:186-188) tests xn < 0 || xn > Lx || ...; a NaN position fails
+  // that test but is no position inside the box either: the time steps count it as outside
+  const bool outside = nan_is_outside ? !(xn >= 0.0 && xn <= Lx && yn >= 0.0 && yn <= Ly)
+                                      : (xn < 0.0 || xn > Lx || yn < 0.0 || yn > Ly);
+  if (out_count && outside) atomicAdd(out_count, 1);
 }
-__global__ void k_advect_move_front(dp uf, dp vf, dp xf, dp yf, cdp u, cdp v, double dx, double dy, double dt, double Lx, double Ly, int nx, int ny, int Nf, int *out_count) {
-  c_advect_move_front(blockIdx.x * blockDim.x + threadIdx.x + 2, uf, vf, xf, yf, u, v, dx, dy, dt, Lx, Ly, nx, ny, Nf, out_count);
+__global__ void k_advect_move_front(dp uf, dp vf, dp xf, dp yf, cdp u, cdp v, double dx, double dy, double dt, double Lx, double Ly, int nx, int ny, int Nf, int *out_count, bool nan_is_outside) {
+  c_advect_move_front(blockIdx.x * blockDim.x + threadIdx.x + 2, uf, vf, xf, yf, u, v, dx, dy, dt, Lx, Ly, nx, ny, Nf, out_count, nan_is_outside);
 }
 
 __global__ void k_close_front(dp xf, dp yf, int Nf) {
@@ -1170,7 +1184,7 @@ extern "C" int nsk_bub_advect_move_front(nsk_ctx *ctx, double *uf, double *vf, d
   int *d_cnt = reinterpret_cast<int *>(ctx->red_dev + 4);
   if (out_of_bounds) NSK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int), ctx->stream));
   k_advect_move_front<<<nsk_cdiv(Nf, 256), 256, 0, ctx->stream>>>(uf, vf, xf, yf, u, v, dx, dy, dt, Lx, Ly, nx, ny, Nf,
-                                                                 out_of_bounds ? d_cnt : nullptr);
+                                                                 out_of_bounds ? d_cnt : nullptr, false);
   NSK_LAUNCH_CHECK();
   k_close_front<<<1, 64, 0, ctx->stream>>>(xf, yf, Nf);
   NSK_LAUNCH_CHECK();
@@ -1196,7 +1210,7 @@ extern "C" int nsk_bub_regrid_front(nsk_ctx *ctx, double *xf, double *yf, double
   NSK_HIP(hipMemcpyAsync(ctx->red_host + 5, d_nf, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   NSK_HIP(hipStreamSynchronize(ctx->stream));
   *Nf_out = *reinterpret_cast<int *>(ctx->red_host + 5);
-  NSK_REQUIRE(*Nf_out >= 0, "regrid_front: the front outgrew its capacity of %d points", cap);
+  NSK_REQUIRE_RC(*Nf_out >= 0, NSK_ERR_FRONT_CAPACITY, "regrid_front: the front outgrew its capacity of %d points", cap);
   return 0;
 }
 
@@ -1289,7 +1303,9 @@ __device__ __forceinline__ T uniform(const T &v) {
 // substeps (surface tension spread to the grid; boundary velocities, predictor, pressure solve,
 // projection, front moved with the new velocity; density jump spread to the grid, density,
 // viscosity), the second-order averaging and the regridding of the front.  words[0..3] receive the
-// sweeps of the four solves, words[4] the new front size (-1: it outgrew the vectors).
+// sweeps of the four solves, words[4] the new front size (-1: it outgrew the vectors; -2: a front
+// point left the box, where the reference's next access by that point is a BoundsError,
+// code3_fun.jl:144-188 -- the step ends there and the state is not to be used).
 // The argument blocks are parked in LDS and every phase reads the pointers and parameters it
 // needs from there: held in registers for the whole launch they would crowd the solvers' loops
 // out of the scalar registers.
@@ -1301,16 +1317,18 @@ __global__ void __launch_bounds__(1024) k_code3_step(nsk_bub_code3_state s_arg, 
   extern __shared__ double lds[];
   __shared__ nsk_bub_code3_state ls;
   __shared__ nsk_bub_params lq;
+  __shared__ int s_outside;  // front points that left the box in this step
   const int tid = threadIdx.x, nth = blockDim.x;
   if (tid == 0) {
     ls = s_arg;
     lq = q_arg;
     if (nf_dev) ls.Nf = *nf_dev;  // a run of steps keeps the front size on the device
+    s_outside = 0;
   }
   __syncthreads();
   auto word = [&](int k) { return reinterpret_cast<int *>(words + k); };  // 8-byte words, an int in each
-  if (uniform(ls.Nf) < 0) {  // an earlier step of the run outgrew the front vectors
-    if (tid == 0) *word(4) = -1;
+  if (uniform(ls.Nf) < 0) {  // an earlier step of the run ended in an error: hand its code on
+    if (tid == 0) *word(4) = ls.Nf;
     return;
   }
   {
@@ -1384,9 +1402,16 @@ __global__ void __launch_bounds__(1024) k_code3_step(nsk_bub_code3_state s_arg, 
       const nsk_bub_code3_state s = uniform(ls);
       const nsk_bub_params q = uniform(lq);
       for (int l = tid + 2; l <= s.Nf + 1; l += nth)
-        c_advect_move_front(l, s.uf, s.vf, s.xf, s.yf, s.u, s.v, q.dx, q.dy, q.dt, q.Lx, q.Ly, q.nx, q.ny, s.Nf, nullptr);
+        c_advect_move_front(l, s.uf, s.vf, s.xf, s.yf, s.u, s.v, q.dx, q.dy, q.dt, q.Lx, q.Ly, q.nx, q.ny, s.Nf, &s_outside, true);
     }
     __syncthreads();
+    if (uniform(s_outside) != 0) {  // the same in every thread; nobody writes it after the barrier
+      if (tid == 0) {
+        *word(4) = -2;
+        if (nf_dev) *nf_dev = -2;
+      }
+      return;
+    }
     {
       const nsk_bub_code3_state s = uniform(ls);
       const nsk_bub_params q = uniform(lq);
@@ -1509,6 +1534,7 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
   const int nx = q->nx, ny = q->ny, Nf = s->Nf;
   NSK_BGRID_OK(nx, ny);
   NSK_REQUIRE(Nf >= 1 && s->cap >= Nf + 2, "nsk_bub_code3_step: front of %d points in vectors of %d", Nf, s->cap);
+  ctx->code3_steps_done = 0;
   const size_t nu = (size_t)(nx + 1) * (ny + 2), nv = (size_t)(nx + 2) * (ny + 1),
                nc = (size_t)(nx + 2) * (ny + 2), nf = (size_t)Nf + 2;
   {
@@ -1528,13 +1554,18 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
       NSK_LAUNCH_CHECK();
       NSK_HIP(hipStreamSynchronize(ctx->stream));
       const int nf_new = host_word(ctx, 4);
-      NSK_REQUIRE(nf_new >= 0, "nsk_bub_code3_step: the front outgrew its capacity of %d points", s->cap);
-      s->Nf = nf_new;
       if (sweeps_out)
         for (int k = 0; k < 4; k++) sweeps_out[k] = host_word(ctx, k);
+      NSK_REQUIRE_RC(nf_new != -2, NSK_ERR_FRONT_OUTSIDE, "nsk_bub_code3_step: a front point left the box [0,%g] x [0,%g]; the state is not to be used", q->Lx, q->Ly);
+      NSK_REQUIRE_RC(nf_new >= 0, NSK_ERR_FRONT_CAPACITY, "nsk_bub_code3_step: the front outgrew its capacity of %d points", s->cap);
+      s->Nf = nf_new;
+      ctx->code3_steps_done = 1;
       return 0;
     }
   }
+  // kernel by kernel: front points that leave the box are counted in a device word read back with the others
+  int *d_outside = step_word(ctx, 5);
+  NSK_HIP(hipMemsetAsync(d_outside, 0, sizeof(int), ctx->stream));
   // un, vn, rn, mn, xfn, yfn = u, v, r, m, xf, yf (:357-362) in one launch
   const Pairs keep{{s->un, s->vn, s->rn, s->mn, s->xfn, s->yfn}, {s->u, s->v, s->r, s->m, s->xf, s->yf},
                    {nu, nv, nc, nc, (size_t)s->cap, (size_t)s->cap}};
@@ -1550,7 +1581,11 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
                             nullptr, nullptr, step_word(ctx, 2 * sub)))
       return rc;
     if (int rc = nsk_bub_correct_vel(ctx, s->u, s->v, s->ut, s->vt, s->p, s->r, q->dt, q->dx, q->dy, nx, ny)) return rc;
-    if (int rc = nsk_bub_advect_move_front(ctx, s->uf, s->vf, s->xf, s->yf, s->u, s->v, q->dx, q->dy, q->dt, q->Lx, q->Ly, nx, ny, Nf, nullptr)) return rc;
+    k_advect_move_front<<<nsk_cdiv(Nf, 256), 256, 0, ctx->stream>>>(s->uf, s->vf, s->xf, s->yf, s->u, s->v, q->dx, q->dy, q->dt, q->Lx,
+                                                                   q->Ly, nx, ny, Nf, d_outside, true);
+    NSK_LAUNCH_CHECK();
+    k_close_front<<<1, 64, 0, ctx->stream>>>(s->xf, s->yf, Nf);
+    NSK_LAUNCH_CHECK();
     if (int rc = nsk_bub_distribute(ctx, s->fx, s->fy, s->xf, s->yf, q->rho1, q->rho2, q->dx, q->dy, nx, ny, Nf)) return rc;
     if (int rc = launch_sor(ctx, 1, s->r, s->fx, s->fy, nullptr, q->beta, q->dx, q->dy, nx, ny, q->maxit, q->maxError,
                             nullptr, nullptr, step_word(ctx, 2 * sub + 1)))
@@ -1567,13 +1602,16 @@ extern "C" int nsk_bub_code3_step(nsk_ctx *ctx, nsk_bub_code3_state *s, const ns
   NSK_HIP(hipMemcpyAsync(d_nf, ctx->red_host + 16, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   k_regrid_front<<<1, 64, 0, ctx->stream>>>(s->xf, s->yf, s->xs, s->ys, q->dx, q->dy, d_nf, s->cap);
   NSK_LAUNCH_CHECK();
-  NSK_HIP(hipMemcpyAsync(ctx->red_host + 8, ctx->red_dev + 8, 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  NSK_HIP(hipMemcpyAsync(ctx->red_host + 8, ctx->red_dev + 8, 6 * 8, hipMemcpyDeviceToHost, ctx->stream));
   NSK_HIP(hipStreamSynchronize(ctx->stream));
-  const int nf_new = host_word(ctx, 4);
-  NSK_REQUIRE(nf_new >= 0, "nsk_bub_code3_step: the front outgrew its capacity of %d points", s->cap);
-  s->Nf = nf_new;
+  // (the clamped indices of the interpolation kept every access of the rest of the step inside the arrays)
   if (sweeps_out)
     for (int k = 0; k < 4; k++) sweeps_out[k] = host_word(ctx, k);
+  NSK_REQUIRE_RC(host_word(ctx, 5) == 0, NSK_ERR_FRONT_OUTSIDE, "nsk_bub_code3_step: a front point left the box [0,%g] x [0,%g]; the state is not to be used", q->Lx, q->Ly);
+  const int nf_new = host_word(ctx, 4);
+  NSK_REQUIRE_RC(nf_new >= 0, NSK_ERR_FRONT_CAPACITY, "nsk_bub_code3_step: the front outgrew its capacity of %d points", s->cap);
+  s->Nf = nf_new;
+  ctx->code3_steps_done = 1;
   return 0;
 }
 
@@ -1643,10 +1681,16 @@ extern "C" int nsk_bub_code3_run(nsk_ctx *ctx, nsk_bub_code3_state *s, const nsk
   const size_t front_bytes = sizeof(double) * 10 * (size_t)s->cap;
   if (front_bytes > lds_bytes) lds_bytes = front_bytes;
   if (!(ctx->bub_merge_launches && plp.ok && plp.pre && pld.ok && lds_bytes <= 156 * 1024) || nsteps == 0) {
-    for (int k = 0; k < nsteps; k++)
-      if (int rc = nsk_bub_code3_step(ctx, s, q, sweeps_out ? sweeps_out + 4 * k : nullptr)) return rc;
+    int done = 0;
+    for (int k = 0; k < nsteps; k++, done++)
+      if (int rc = nsk_bub_code3_step(ctx, s, q, sweeps_out ? sweeps_out + 4 * k : nullptr)) {
+        ctx->code3_steps_done = done;
+        return rc;
+      }
+    ctx->code3_steps_done = done;
     return 0;
   }
+  ctx->code3_steps_done = 0;
   unsigned long long *words = nullptr;
   if (int rc = run_words(ctx, nsteps, &words)) return rc;
   if (int rc = pipe_reserve(ctx, plp, nx, ny)) return rc;
@@ -1666,10 +1710,18 @@ extern "C" int nsk_bub_code3_run(nsk_ctx *ctx, nsk_bub_code3_state *s, const nsk
   NSK_HIP(hipStreamSynchronize(ctx->stream));
   for (int k = 0; k < nsteps; k++) {
     const int nf = (int)(unsigned)host[8 * (size_t)k + 4];
-    NSK_REQUIRE(nf >= 0, "nsk_bub_code3_run: the front outgrew its capacity of %d points in step %d of the run", s->cap, k + 1);
-    s->Nf = nf;
     if (sweeps_out)
       for (int j = 0; j < 4; j++) sweeps_out[4 * k + j] = (int)(unsigned)host[8 * (size_t)k + j];
+    NSK_REQUIRE_RC(nf != -2, NSK_ERR_FRONT_OUTSIDE, "nsk_bub_code3_run: a front point left the box [0,%g] x [0,%g] in step %d of the run; the state is not to be used", q->Lx, q->Ly, k + 1);
+    NSK_REQUIRE_RC(nf >= 0, NSK_ERR_FRONT_CAPACITY, "nsk_bub_code3_run: the front outgrew its capacity of %d points in step %d of the run", s->cap, k + 1);
+    s->Nf = nf;
+    ctx->code3_steps_done = k + 1;
   }
+  return 0;
+}
+
+extern "C" int nsk_bub_code3_run_status(nsk_ctx *ctx, int *steps_done) {
+  NSK_REQUIRE(ctx != nullptr && steps_done != nullptr, "nsk_bub_code3_run_status: null argument");
+  *steps_done = ctx->code3_steps_done;
   return 0;
 }

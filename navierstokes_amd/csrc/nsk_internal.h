@@ -61,6 +61,7 @@ struct nsk_ctx {
   } lds_allowed[16] = {};
   int step_fused = 1;    // nsk_ns_step: 1 = three fused kernels around the Poisson loop, 0 = one launch per call site
   int poisson_rows = 0;  // rows per task chunk, 0 = automatic (NSK_POISSON_ROWS / nsk_set_option)
+  int code3_steps_done = 0;  // complete time steps of the last nsk_bub_code3_step / _run call
 };
 
 void nsk_set_error(const char *fmt, ...);
@@ -100,6 +101,15 @@ inline hipError_t nsk_allow_lds(nsk_ctx *ctx, const void *kernel, size_t bytes) 
     if (!(cond)) {                                                             \
       nsk_set_error(__VA_ARGS__);                                              \
       return 2;                                                                \
+    }                                                                          \
+  } while (0)
+
+// as NSK_REQUIRE with a return value of its own (NSK_ERR_* of include/nsk.h)
+#define NSK_REQUIRE_RC(cond, rc, ...)                                          \
+  do {                                                                         \
+    if (!(cond)) {                                                             \
+      nsk_set_error(__VA_ARGS__);                                              \
+      return (rc);                                                             \
     }                                                                          \
   } while (0)
 

@@ -22,14 +22,6 @@ not produced at all, and the rest of the window runs on the main stream; the exc
 behind the second stream only, so the rows travel while the last launch is still running.  No
 extra arithmetic, same values.
 
-The older "bands" schedule hides the transfer behind a whole block instead: each
-block first advances a *band* of 3*halo rows around each interior edge (a copy of those rows,
-run as a window of its own on a second stream): after the block's passes its middle
-`halo` rows are exactly the rows to send.  They travel on a communication stream while the
-main stream runs the same passes on the whole window; the received rows are installed in the
-halo when both are done.  Bands cost 6*halo extra rows per block and rank; every value is still
-produced by the same expression from the same inputs, so results do not change by a bit.
-
 The compute backend is injected (`backend`): the product passes the HIP library binding; the
 CPU tests pass a stand-in so that the decomposition and the exchange run under gloo.
 """
@@ -150,73 +142,33 @@ def allreduce_maxabs(value: float, device) -> float:
     return struct.unpack("<d", struct.pack("<q", int(t.item())))[0]
 
 
-class Band:
-    """3*halo window rows around one interior edge of a slab, advanced ahead of the window so that
-    its middle `halo` rows (the owned rows the neighbour needs) can be sent while the window is
-    still being computed.  Quacks like a Slab for the backend (iy0, nyg, ny_win)."""
-
-    def __init__(self, slab: Slab, low: bool, like: torch.Tensor):
-        h = slab.halo
-        self.low, self.h = low, h
-        self.start = 0 if low else slab.own_hi - 2 * h       # first window row of the band
-        self.ny_win = 3 * h
-        self.iy0, self.nyg = slab.iy0 + self.start, slab.nyg
-        self.peer = slab.rank - 1 if low else slab.rank + 1
-        self.halo_at = 0 if low else slab.own_hi             # window rows the received rows go to
-        ld = like.shape[1]
-        z = lambda rows: torch.zeros((rows, ld), dtype=like.dtype, device=like.device)
-        self.Pr, self.dP = z(3 * h), z(3 * h)
-        self.recv_Pr, self.recv_dP = z(h), z(h)
-
-    @property
-    def rows(self) -> slice:
-        return slice(self.start, self.start + self.ny_win)
-
-    @property
-    def send(self) -> slice:
-        """band rows that hold the owned rows next to the edge"""
-        return slice(self.h, 2 * self.h)
-
-
 class SlabPoisson:
     """Poisson loop of one rank.  `backend` provides
-        poisson_iters(Pr, dP, divV, window, count, lane=0)  -- `count` passes on the window (in place);
-                                                               lane 1 = the band stream
-        residual_max(Pr, divV, slab) -> float               -- max|Rp| over the owned rows
-    on tensors shaped (ny_win, ld); `window` is a Slab or a Band (iy0, nyg, ny_win).
+        poisson_iters(Pr, dP, divV, window, count)   -- `count` passes on the window (in place)
+        residual_max(Pr, divV, slab) -> float        -- max|Rp| over the owned rows
+    on tensors shaped (ny_win, ld); `window` is a Slab (iy0, nyg, ny_win).
 
     schedule: "plain" = passes, then the exchange; "edges" = the rows to be sent are produced first in
     the last launch of a block and travel beside the rest of it (needs a backend with
-    poisson_iters_edges and more than 2*halo owned rows per rank); "bands" = boundary bands ahead
-    of the window (needs 2*halo owned rows per rank; on one MI355X it costs more than it can hide:
-    the window's launches fill every wavefront slot of the chip, so band launches push them back,
-    tools/overlap_overhead.py).  None = "edges" where possible, else "plain".  overlap=True is the
-    old spelling of schedule="bands", overlap="auto" of "bands where the geometry allows"."""
+    poisson_iters_edges and more than 2*halo owned rows per rank).  None = "edges" where possible,
+    else "plain"."""
 
-    def __init__(self, p: NSParams, slab: Slab, backend, Pr, dP, divV, overlap=False, schedule=None):
+    def __init__(self, p: NSParams, slab: Slab, backend, Pr, dP, divV, schedule=None):
         self.p, self.slab, self.be = p, slab, backend
         self.Pr, self.dP, self.divV = Pr, dP, divV
-        fits = slab.world > 1 and slab.ny_loc >= 2 * slab.halo
-        if schedule is None and overlap:
-            schedule = "bands" if (overlap is True or fits) else "plain"
         can_edges = (slab.world > 1 and slab.ny_loc > 2 * slab.halo and Pr.is_cuda
                      and hasattr(backend, "poisson_iters_edges"))
         if schedule is None:
             schedule = "edges" if can_edges else "plain"
-        if schedule not in ("plain", "edges", "bands"):
+        if schedule not in ("plain", "edges"):
             raise ValueError(f"unknown schedule {schedule!r}")
-        if schedule == "bands" and slab.world > 1 and not fits:
-            raise ValueError(f"overlapped exchange needs at least 2*halo = {2 * slab.halo} owned rows per rank, "
-                             f"got {slab.ny_loc}")
         if schedule == "edges" and slab.world > 1 and not can_edges:
             raise ValueError("the edges-first schedule needs the HIP backend and more than 2*halo owned rows per rank")
         if slab.world == 1:
             schedule = "plain"
         self.schedule = schedule
-        self.overlap = schedule == "bands"
         if schedule == "edges":
             self.edge_stream = torch.cuda.Stream(device=Pr.device)
-        self.bands = []
         self.exchanges = 0
         self.timing = False          # True: keep an event pair per exchange (exposed_us())
         self.loopback = False        # True: no peers; halo rows are refilled by device copies of the
@@ -224,19 +176,6 @@ class SlabPoisson:
         self.loopback_wire = 0       # loopback only: spin this many torch.cuda._sleep cycles where the
                                      # transfer would run (a stand-in for latency + wire time)
         self._marks = []
-        if self.overlap:
-            if slab.rank > 0:
-                self.bands.append(Band(slab, True, Pr))
-            if slab.rank < slab.world - 1:
-                self.bands.append(Band(slab, False, Pr))
-            if Pr.is_cuda:
-                # Ordinary priority on purpose: with a high-priority band stream the second
-                # SlabPoisson of a process stalled for good on MI355X (ROCm 7.2) -- all three streams
-                # pending on each other's events -- while equal priorities never did.
-                self.band_stream = torch.cuda.Stream(device=Pr.device)
-                self.comm_stream = torch.cuda.Stream(device=Pr.device)
-                if hasattr(backend, "use_band_stream"):
-                    backend.use_band_stream(self.band_stream)
 
     # -- one block of n <= halo passes followed by the halo refresh ------------------------------
     def _block_plain(self, n: int) -> None:
@@ -285,63 +224,6 @@ class SlabPoisson:
                 r.wait()                                   # the main stream (not the host) waits
         self._mark(mark)
 
-    def _block_overlapped(self, n: int) -> None:
-        cuda = self.Pr.is_cuda
-        main = torch.cuda.current_stream(self.Pr.device) if cuda else None
-        for b in self.bands:                               # the block's starting state of the band rows
-            b.Pr.copy_(self.Pr[b.rows])
-            b.dP.copy_(self.dP[b.rows])
-        if cuda:
-            self.band_stream.wait_stream(main)
-        for b in self.bands:                               # divV is read-only: the band reads the window's rows
-            self.be.poisson_iters(b.Pr, b.dP, self.divV[b.rows], b, n, lane=1)
-        self.be.poisson_iters(self.Pr, self.dP, self.divV, self.slab, n)
-        mark = self._mark()
-        if self.loopback:
-            if cuda:
-                self.comm_stream.wait_stream(self.band_stream)
-                with torch.cuda.stream(self.comm_stream):
-                    for b in self.bands:
-                        b.recv_Pr.copy_(b.Pr[b.send])
-                        b.recv_dP.copy_(b.dP[b.send])
-                main.wait_stream(self.comm_stream)
-            self._install(mark)
-            return
-        gloo = dist.get_backend() == "gloo"
-        stage = cuda and gloo
-        if cuda and gloo:
-            self.band_stream.synchronize()                 # host-staged transport reads the band rows now
-        ops, landing = [], []
-        for b in self.bands:
-            for src, dst in ((b.Pr, b.recv_Pr), (b.dP, b.recv_dP)):
-                ops.append(dist.P2POp(dist.isend, src[b.send].cpu() if stage else src[b.send], b.peer))
-                if stage:
-                    buf = torch.empty_like(dst, device="cpu")
-                    landing.append((dst, buf))
-                    ops.append(dist.P2POp(dist.irecv, buf, b.peer))
-                else:
-                    ops.append(dist.P2POp(dist.irecv, dst, b.peer))
-        if cuda and not gloo:
-            # RCCL: the transfer is ordered after the band stream and runs beside the main stream
-            self.comm_stream.wait_stream(self.band_stream)
-            with torch.cuda.stream(self.comm_stream):
-                reqs = dist.batch_isend_irecv(ops)
-            for r in reqs:
-                r.wait()                                   # the main stream (not the host) waits
-        else:
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
-            for dst, buf in landing:
-                dst.copy_(buf)
-        self._install(mark)
-
-    def _install(self, mark) -> None:
-        for b in self.bands:
-            h = b.h
-            self.Pr[b.halo_at:b.halo_at + h].copy_(b.recv_Pr)
-            self.dP[b.halo_at:b.halo_at + h].copy_(b.recv_dP)
-        self._mark(mark)
-
     def _mark(self, first=None):
         """Event pair around the part of an exchange the main stream cannot hide."""
         if not (self.timing and self.Pr.is_cuda):
@@ -371,9 +253,7 @@ class SlabPoisson:
         left = count
         while left > 0:
             n = min(left, s.halo)
-            if self.schedule == "bands":
-                self._block_overlapped(n)
-            elif self.schedule == "edges":
+            if self.schedule == "edges":
                 self._block_edges(n)
             else:
                 self._block_plain(n)
@@ -408,15 +288,6 @@ class HipBackend:
         import ctypes as C
         from .ns import c_params
         self.C, self.ctx, self.p, self.ld, self._c_params = C, ctx, p, ld, c_params
-        self.ctx_band = None
-
-    def use_band_stream(self, stream) -> None:
-        """A second library context on `stream` (its own ping-pong partners) for the boundary bands."""
-        from . import _lib
-        if self.ctx_band is not None:
-            self.ctx_band.close()
-        self.ctx_band = _lib.Context(stream.device.index or 0, stream.cuda_stream)
-        self._band_stream = stream       # keeps the stream alive as long as the context uses it
 
     @staticmethod
     def _P(t):
@@ -462,11 +333,10 @@ class HipBackend:
         return self._c_params(self.p, ld_pr=self.ld, dp_embedded=1, iy0=slab.iy0, nyg=slab.nyg,
                               ny=slab.ny_win)
 
-    def poisson_iters(self, Pr, dP, divV, slab, count, lane=0):
+    def poisson_iters(self, Pr, dP, divV, slab, count):
         C = self.C
         cp = self._cp(slab)
-        ctx = self.ctx if lane == 0 else self.ctx_band
-        ctx.ns_poisson_iters(C.c_void_p(Pr.data_ptr()), C.c_void_p(dP.data_ptr()),
+        self.ctx.ns_poisson_iters(C.c_void_p(Pr.data_ptr()), C.c_void_p(dP.data_ptr()),
                              C.c_void_p(divV.data_ptr()), C.byref(cp), int(count))
 
     def poisson_iters_edges(self, Pr, dP, divV, slab, count, edge_stream):
@@ -506,7 +376,7 @@ class SlabNavierStokes:
         poisson_iters, residual_max                          (see SlabPoisson)
     """
 
-    def __init__(self, p: NSParams, slab: Slab, backend, device, ld: int, vprof, overlap=False, schedule=None):
+    def __init__(self, p: NSParams, slab: Slab, backend, device, ld: int, vprof, schedule=None):
         self.p, self.slab, self.be, self.dev, self.ld = p, slab, backend, device, ld
         if slab.world > 1 and slab.halo < 4:
             # advect! needs reach + 1 <= halo - 1 valid rows and reach >= 2 (see step())
@@ -522,7 +392,7 @@ class SlabNavierStokes:
         self.Vprof = torch.as_tensor(vprof, dtype=torch.float64).to(device)
         if slab.iy0 == 0:
             self.Vy[0, :] = self.Vprof          # NavierStokes.jl:73
-        self.poisson = SlabPoisson(p, slab, backend, self.Pr, self.dP, self.divV, overlap=overlap, schedule=schedule)
+        self.poisson = SlabPoisson(p, slab, backend, self.Pr, self.dP, self.divV, schedule=schedule)
         self.hist = []
 
     def step(self) -> int:

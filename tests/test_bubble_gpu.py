@@ -360,11 +360,17 @@ def test_runs_of_steps(merged):
             assert same_bits(getattr(g3, k).get(), getattr(o3, k)), k
         (gx, gy), (ox, oy) = g3.front(), o3.front()
         assert same_bits(gx, ox) and same_bits(gy, oy)
-        # a front that outgrows its vectors in the middle of a run is an error of the run
-        from navierstokes_amd import _lib
-        g4 = Code3(Code3Params(nx=48, ny=48, Nf=40, cap=48))
-        with pytest.raises(_lib.NskError, match="outgrew its capacity"):
-            g4.run(4)
+        # a front that outgrows its vectors in the middle of a run gets larger ones, as the reference's
+        # resize! does (code3_fun.jl:462-465), and the run goes on from the step that needed them
+        from dataclasses import replace
+        q4 = Code3Params(nx=48, ny=48, Nf=40, cap=48)
+        g4, o4 = Code3(q4), OracleCode3(replace(q4, cap=4096))
+        assert g4.run(6) == [o4.step() for _ in range(6)] and g4.Nf == o4.Nf
+        assert g4.grown >= 1 and g4.cap > 48 and g4.Nf + 2 > 48
+        for k in ("r", "m", "u", "v", "p"):
+            assert same_bits(getattr(g4, k).get(), getattr(o4, k)), k
+        (gx, gy), (ox, oy) = g4.front(), o4.front()
+        assert same_bits(gx, ox) and same_bits(gy, oy)
     finally:
         g.ctx.set_option("bub_merge_launches", 1)
 
@@ -380,7 +386,74 @@ def test_fused_steps_report_their_errors(gpu):
     g.Nf = 63
     with pytest.raises(_lib.NskError, match="front of 63 points in vectors of 64"):
         g.step()
-    g = Code3(Code3Params(nx=48, ny=48, Nf=40, cap=48))      # coarse front on a fine grid: regridding doubles it
-    with pytest.raises(_lib.NskError, match="outgrew its capacity"):
+    # coarse front on a fine grid: regridding doubles it.  The C entry points report it with a code of
+    # their own and leave the step complete but for the regridding ...
+    g = Code3(Code3Params(nx=48, ny=48, Nf=40, cap=48))
+    st, pr = g._c_args()
+    with pytest.raises(_lib.NskError, match="outgrew its capacity") as e:
+        gpu_steps = 0
         for _ in range(3):
+            g.ctx.bub_code3_step(C.byref(st), C.byref(pr), None)
+            gpu_steps += 1
+    assert e.value.code == _lib.ERR_FRONT_CAPACITY and g._steps_done() == 0 and st.Nf + 2 <= 48
+    st, pr = Code3(Code3Params(nx=48, ny=48, Nf=40, cap=48))._c_args()
+    with pytest.raises(_lib.NskError, match="outgrew its capacity") as e:
+        g.ctx.bub_code3_run(C.byref(st), C.byref(pr), 4, None)
+    assert e.value.code == _lib.ERR_FRONT_CAPACITY
+
+
+@pytest.mark.parametrize("form", STEP_FORMS)
+def test_code3_front_grows_like_the_reference(form):
+    """code3_fun.jl:462-465 resizes xf, yf when the regridding runs out of room.  The host driver does the
+    same for every form of the step: the fields and the front equal the oracle's, which is given room
+    from the start."""
+    from dataclasses import replace
+    q = Code3Params(nx=48, ny=48, Nf=40, cap=48)
+    g, o = Code3(q), OracleCode3(replace(q, cap=4096))
+    step_form(g, form)
+    try:
+        for _ in range(5):
+            assert g.step() == o.step()
+            assert g.Nf == o.Nf
+    finally:
+        g.ctx.set_option("bub_merge_launches", 1)
+    assert g.grown >= 1
+    for k in ("r", "m", "u", "v", "p"):
+        assert same_bits(getattr(g, k).get(), getattr(o, k)), k
+    (gx, gy), (ox, oy) = g.front(), o.front()
+    assert same_bits(gx, ox) and same_bits(gy, oy)
+
+
+@pytest.mark.parametrize("form", STEP_FORMS)
+def test_code3_front_leaving_the_box_is_an_error(form):
+    """A front point that leaves [0,Lx] x [0,Ly]: the reference prints a message (code3_fun.jl:186-188) and
+    its next array access by that point throws; the oracle stops with FrontLeftTheBox; the step and the
+    run entry points return NSK_ERR_FRONT_OUTSIDE in the same time step."""
+    from navierstokes_amd import _lib
+    from oracle.bubble_oracle import FrontLeftTheBox
+    # one pressure sweep per solve leaves the velocity far from divergence-free: the drop is torn out of
+    # the cavity in the third time step
+    q = Code3Params(nx=16, ny=24, gy=-30.0, gx=5.0, rho2=3.82, veast=0.3, vwest=-0.3, rad=0.169, maxit=1, beta=1.34,
+                    xc=0.555, yc=0.562, Nf=57, sigma=0.0, dt0=0.0022222222222222222)
+    o, n_ok = OracleCode3(q), 0
+    with pytest.raises(FrontLeftTheBox):
+        for _ in range(8):
+            o.step()
+            n_ok += 1
+    assert n_ok == 2
+    g = Code3(q)
+    step_form(g, form)
+    try:
+        for _ in range(n_ok):
             g.step()
+        with pytest.raises(_lib.NskError, match="left the box") as e:
+            g.step()
+        assert e.value.code == _lib.ERR_FRONT_OUTSIDE
+        if g.fused:
+            g2 = Code3(q)
+            step_form(g2, form)
+            with pytest.raises(_lib.NskError, match=f"left the box.* in step {n_ok + 1} of the run|left the box") as e:
+                g2.run(n_ok + 3)
+            assert e.value.code == _lib.ERR_FRONT_OUTSIDE and g2._steps_done() == n_ok
+    finally:
+        g.ctx.set_option("bub_merge_launches", 1)

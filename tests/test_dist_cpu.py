@@ -26,7 +26,7 @@ class OracleWindowBackend:
     def _f(t, nx):     # (ny_win, ld) torch tensor -> Fortran (nx, ny_win) copy
         return np.asfortranarray(t[:, :nx].numpy().T)
 
-    def poisson_iters(self, Pr, dP, divV, slab, count, lane=0):
+    def poisson_iters(self, Pr, dP, divV, slab, count):
         p, o, nx = self.p, self.o, self.p.nx
         a, d, v = self._f(Pr, nx), self._f(dP, nx), self._f(divV, nx)
         din = np.asfortranarray(d[1:-1, 1:-1])
@@ -119,7 +119,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, halo, overlap, nx, ny_loc, niter, nchk, out):
+def _worker(rank, world, port, halo, nx, ny_loc, niter, nchk, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -142,8 +142,8 @@ def _worker(rank, world, port, halo, overlap, nx, ny_loc, niter, nchk, out):
         if slab.hi_halo:
             Pr[slab.own_hi:] = -777.0
         exchange_rows((Pr,), slab)
-        sp = SlabPoisson(p, slab, OracleWindowBackend(p), Pr, dP, divV, overlap=overlap)
-        assert sp.overlap == overlap and len(sp.bands) == (overlap and (rank > 0) + (rank < world - 1))
+        sp = SlabPoisson(p, slab, OracleWindowBackend(p), Pr, dP, divV)
+        assert sp.schedule == "plain"          # the edges-first schedule needs the HIP backend
         done, hist = sp.solve()
         assert sp.exchanges == sum(-(-c // halo) for c in [nchk] * (done // nchk) + [done % nchk])
         own = slice(slab.own_lo, slab.own_hi)
@@ -158,15 +158,13 @@ def _worker(rank, world, port, halo, overlap, nx, ny_loc, niter, nchk, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,halo,overlap", [(2, 4, False), (2, 4, True), (2, 7, False), (3, 5, True), (3, 6, True),
-                                                (4, 3, True)])
-def test_slab_poisson_matches_single_domain(tmp_path, world, halo, overlap):
-    """Plain schedule (passes, then a blocking exchange) and overlapped schedule (boundary bands
-    ahead of the window, their rows sent while the window is computed); block lengths that do and
-    do not divide the check interval; a rank that owns exactly 2*halo rows."""
+@pytest.mark.parametrize("world,halo", [(2, 4), (2, 7), (3, 5), (3, 6), (4, 3)])
+def test_slab_poisson_matches_single_domain(tmp_path, world, halo):
+    """Passes, then a blocking exchange; block lengths that do and do not divide the check interval;
+    a rank that owns exactly 2*halo rows."""
     from oracle.ns_oracle import Oracle
     nx, ny_loc, niter, nchk = 17, 12, 60, 20
-    mp.spawn(_worker, args=(world, _free_port(), halo, overlap, nx, ny_loc, niter, nchk, str(tmp_path)), nprocs=world,
+    mp.spawn(_worker, args=(world, _free_port(), halo, nx, ny_loc, niter, nchk, str(tmp_path)), nprocs=world,
              join=True)
     nyg = ny_loc * world
     p = ns_params("NavierStokes", nx=nx, ny=nyg, niter=niter, nchk=nchk)
@@ -186,7 +184,7 @@ def test_slab_poisson_matches_single_domain(tmp_path, world, halo, overlap):
     assert np.array_equal(gotdP[1:-1, 1:-1], dP)
 
 
-def _step_worker(rank, world, port, halo, overlap, nx, ny_loc, steps, out):
+def _step_worker(rank, world, port, halo, nx, ny_loc, steps, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -195,9 +193,7 @@ def _step_worker(rank, world, port, halo, overlap, nx, ny_loc, steps, out):
         nyg = ny_loc * world
         p = ns_params("NavierStokes", nx=nx, ny=nyg, niter=40, nchk=10)
         slab = make_slab(rank, world, ny_loc, halo)
-        sim = SlabNavierStokes(p, slab, OracleWindowBackend(p), torch.device("cpu"), nx + 1, init_vprof(p),
-                               overlap=overlap)
-        assert sim.poisson.overlap == overlap
+        sim = SlabNavierStokes(p, slab, OracleWindowBackend(p), torch.device("cpu"), nx + 1, init_vprof(p))
         iters = [sim.step() for _ in range(steps)]
         res = {k: sim.owned(k)[:, : {"Vx": nx + 1}.get(k, nx)].clone() for k in ("Pr", "Vx", "Vy", "C", "dP")}
         res["iters"], res["hist"] = iters, sim.hist
@@ -206,12 +202,12 @@ def _step_worker(rank, world, port, halo, overlap, nx, ny_loc, steps, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,halo,overlap", [(2, 6, True), (2, 6, False), (3, 5, True)])
-def test_slab_time_steps_match_single_domain(tmp_path, world, halo, overlap):
+@pytest.mark.parametrize("world,halo", [(2, 6), (3, 5)])
+def test_slab_time_steps_match_single_domain(tmp_path, world, halo):
     """Whole time steps (NavierStokes.jl:77-100) on slabs == the single-domain oracle."""
     from oracle.ns_oracle import OracleSim
     nx, ny_loc, steps = 13, 12, 3
-    mp.spawn(_step_worker, args=(world, _free_port(), halo, overlap, nx, ny_loc, steps, str(tmp_path)), nprocs=world,
+    mp.spawn(_step_worker, args=(world, _free_port(), halo, nx, ny_loc, steps, str(tmp_path)), nprocs=world,
              join=True)
     p = ns_params("NavierStokes", nx=nx, ny=ny_loc * world, niter=40, nchk=10)
     ref = OracleSim(p)
@@ -239,9 +235,9 @@ def test_slab_geometry_rejects_unusable_halos():
     p = ns_params("NavierStokes", nx=9, ny=80)
     with pytest.raises(ValueError, match="at least 4 halo rows"):
         SlabNavierStokes(p, make_slab(0, 2, 40, 3), None, "cpu", 9, np.zeros(9))
-    z = torch.zeros((40 + 21, 9), dtype=torch.float64)
-    with pytest.raises(ValueError, match="overlapped exchange needs"):
-        SlabPoisson(p, make_slab(0, 2, 40, 21), None, z, z, z, overlap=True)
-    assert not SlabPoisson(p, make_slab(0, 2, 40, 21), None, z, z, z, overlap="auto").overlap     # falls back
-    assert SlabPoisson(p, make_slab(0, 2, 40, 20), None, z[:60], z[:60], z[:60], overlap="auto").overlap
-    assert not SlabPoisson(p, make_slab(0, 2, 40, 20), None, z[:60], z[:60], z[:60]).overlap    # default: plain
+    z = torch.zeros((60, 9), dtype=torch.float64)
+    with pytest.raises(ValueError, match="unknown schedule"):
+        SlabPoisson(p, make_slab(0, 2, 40, 20), None, z, z, z, schedule="bands")
+    with pytest.raises(ValueError, match="edges-first schedule needs"):
+        SlabPoisson(p, make_slab(0, 2, 40, 20), None, z, z, z, schedule="edges")     # CPU tensors, no HIP backend
+    assert SlabPoisson(p, make_slab(0, 2, 40, 20), None, z, z, z).schedule == "plain"

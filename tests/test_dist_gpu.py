@@ -53,13 +53,11 @@ def _worker(rank, world, port, halo, schedule, nx, ny_loc, steps, niter, nchk, o
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,halo,schedule,nx,ny_loc", [(2, 8, "plain", 45, 40), (2, 8, "bands", 45, 40),
-                                                          (3, 12, "bands", 54, 30), (3, 15, "bands", 54, 30),
+@pytest.mark.parametrize("world,halo,schedule,nx,ny_loc", [(2, 8, "plain", 45, 40), (3, 15, "plain", 54, 30),
                                                           (2, 8, None, 45, 40), (3, 12, "edges", 54, 30),
                                                           (3, 14, "edges", 70, 44), (4, 5, "edges", 33, 24)])
 def test_slab_time_steps_on_gpu(tmp_path, world, halo, schedule, nx, ny_loc):
-    """bands: boundary bands run ahead on a second stream through a second library context while
-    the window is computed on the main stream; edges (the default, None): the last launch of every
+    """plain: passes, then the exchange; edges (the default, None): the last launch of every
     block produces the rows to be sent first, on a second stream, and leaves the halo rows to the
     exchange.  Results must not change by a bit."""
     from oracle.ns_oracle import OracleSim
@@ -81,7 +79,7 @@ def test_slab_time_steps_on_gpu(tmp_path, world, halo, schedule, nx, ny_loc):
 
 
 def test_rccl_branch_of_every_schedule_to_self():
-    """The torch.distributed/RCCL branch of the three slab schedules as far as one GPU can take it: a
+    """The torch.distributed/RCCL branch of the two slab schedules as far as one GPU can take it: a
     one-rank `nccl` process group, every isend/irecv of an interior rank addressed to itself, against
     the same run with the halo rows refilled by device copies (tools/rccl_self_rehearsal.py).  Runs in
     a process of its own (the process group is process-wide) under a time limit, so that a stalled
@@ -91,6 +89,6 @@ def test_rccl_branch_of_every_schedule_to_self():
     r = subprocess.run([sys.executable, "-u", tool, "95", "60", "8", "40"], env=env, timeout=100,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
-    for schedule in ("plain", "edges", "bands"):
+    for schedule in ("plain", "edges"):
         assert f"{schedule:6s} RCCL-to-self == loopback: True" in r.stdout, r.stdout[-3000:]
     assert "all-reduce keeps NaN: True" in r.stdout

@@ -2,12 +2,11 @@
 """Compute-side cost of the slab schedules on ONE GPU: an interior rank (two neighbours) of a
 2559 x 4095-per-rank decomposition runs `passes` Poisson passes with its halo rows refilled by
 device copies instead of peers (loopback), so everything but the wire is timed: redundant halo
-rows, the cut last launch of the edges-first schedule, the boundary bands of the bands schedule
-and how they disturb the window's launches, the install copies.  With a wire time (us) a spin
+rows and the cut last launch of the edges-first schedule.  With a wire time (us) a spin
 kernel of that length stands where the transfer would run, which shows what each schedule hides.
 Prints us per pass against the single-domain loop.
 
-  python tools/overlap_overhead.py [passes] [wire_us] [halo:schedule ...]    schedule p | e | b"""
+  python tools/overlap_overhead.py [passes] [wire_us] [halo:schedule ...]    schedule p | e"""
 import os
 import sys
 import time
@@ -56,8 +55,8 @@ def run(p, halo, schedule, passes, world=3, rank=1, wire=0):
     sp.timing = True
     if os.environ.get("NSK_DEBUG_POLL"):
         streams = {"main": torch.cuda.current_stream()}
-        if sp.schedule == "bands":
-            streams.update(band=sp.band_stream, comm=sp.comm_stream)
+        if sp.schedule == "edges":
+            streams.update(edge=sp.edge_stream)
         for i in range(8):
             state = {k: v.query() for k, v in streams.items()}
             print("poll", i, state, flush=True)
@@ -81,9 +80,9 @@ def main():
     faulthandler.dump_traceback_later(45, exit=True)     # a stuck run says where and ends
     passes = int(sys.argv[1]) if len(sys.argv) > 1 else 2400
     wire_us = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
-    cases = [(60, "plain"), (60, "edges"), (120, "plain"), (120, "edges"), (24, "bands")]
+    cases = [(60, "plain"), (60, "edges"), (120, "plain"), (120, "edges")]
     if len(sys.argv) > 3:
-        names = {"p": "plain", "e": "edges", "b": "bands"}
+        names = {"p": "plain", "e": "edges"}
         cases = [(int(h), names[o]) for h, o in (c.split(":") for c in sys.argv[3:])]
     p = ns_params("NavierStokes_Re6", n=16)
     torch.cuda.set_device(0)
