@@ -79,6 +79,12 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *   "sor_pipeline"         nsk_bub_solve_pressure / nsk_bub_construct_den: 1 = several lexicographic sweeps
  *                          in flight on the anti-diagonals when the grid fits LDS (default), 0 = one
  *                          sweep at a time; same results
+ *   "sor_grid"             the same two solvers on grids beyond one workgroup's LDS: 1 = tiles of 64 x
+ *                          "sor_grid_rows" cells on the whole chip, several sweeps in flight (default),
+ *                          0 = one workgroup, one sweep at a time; same results
+ *   "sor_grid_rows"        tile height of that solver (4..64, 0 = 32)
+ *   "sor_grid_copies"      copies of the unknown that solver keeps (one per sweep in flight; 0 = by the grid,
+ *                          else >= 3: fewer copies than sweeps fit in flight, for tests)
  *   "sor_fast_division"    the sweeps-in-flight pressure solve: 1 = quotients by the face coefficients through
  *                          their reciprocals and two fused corrections, which gives the bits of the IEEE
  *                          division while operands stay in [2^-900, 2^900] (else the solve is repeated

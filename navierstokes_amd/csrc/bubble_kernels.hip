@@ -958,6 +958,19 @@ int launch_sor(nsk_ctx *ctx, int mode, double *a, const double *c1, const double
       return 0;
     }
   }
+  if (ctx->sor_grid) {
+    // larger grids: tiles on the whole chip, several sweeps in flight (bubble_sor_grid.hip)
+    if (int rc = nsk_sor_grid(ctx, mode, a, c1, c2, c3, beta, dx, dy, nx, ny, maxit, maxError, d_sweeps, d_change)) return rc;
+    if (sweeps || change) {
+      NSK_HIP(hipMemcpyAsync(ctx->red_host + 2, ctx->red_dev + 2, 16, hipMemcpyDeviceToHost, ctx->stream));
+      NSK_HIP(hipStreamSynchronize(ctx->stream));
+      const int n = *reinterpret_cast<int *>(ctx->red_host + 2);
+      NSK_REQUIRE_RC(n >= 0 || dev_sweeps, NSK_ERR_HIP, "SOR: a wait inside the solve ran out (no progress on the device)");
+      if (sweeps) *sweeps = n;
+      if (change) *change = *reinterpret_cast<double *>(ctx->red_host + 3);
+    }
+    return 0;
+  }
   const bool use_lds = bytes <= 128 * 1024;
   const size_t all_bytes = bytes * (mode == 0 ? 4 : 3);
   const bool coef_lds = all_bytes <= 144 * 1024;

@@ -71,6 +71,7 @@ extern "C" int nsk_destroy(nsk_ctx *c) {
   if (c->stage) (void)hipFree(c->stage);
   if (c->iter_pp) (void)hipFree(c->iter_pp);
   if (c->sor_snap) (void)hipFree(c->sor_snap);
+  if (c->sor_grid_ctl) (void)hipFree(c->sor_grid_ctl);
   if (c->run_words) (void)hipFree(c->run_words);
   if (c->ev_edge) (void)hipEventDestroy(c->ev_edge);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -123,6 +124,20 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
   }
   if (!strcmp(name, "sor_pipeline")) {
     ctx->sor_pipeline = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "sor_grid")) {
+    ctx->sor_grid = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "sor_grid_rows")) {
+    NSK_REQUIRE(value >= 0 && value <= 64, "sor_grid_rows: %d (0 = default, else 4..64)", value);
+    ctx->sor_grid_rows = value;
+    return 0;
+  }
+  if (!strcmp(name, "sor_grid_copies")) {
+    NSK_REQUIRE(value == 0 || value >= 3, "sor_grid_copies: %d (0 = by the grid, else >= 3)", value);
+    ctx->sor_grid_copies = value;
     return 0;
   }
   if (!strcmp(name, "sor_fast_division")) {
@@ -178,6 +193,18 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   }
   if (!strcmp(name, "sor_pipeline")) {
     *value = ctx->sor_pipeline;
+    return 0;
+  }
+  if (!strcmp(name, "sor_grid")) {
+    *value = ctx->sor_grid;
+    return 0;
+  }
+  if (!strcmp(name, "sor_grid_rows")) {
+    *value = ctx->sor_grid_rows;
+    return 0;
+  }
+  if (!strcmp(name, "sor_grid_copies")) {
+    *value = ctx->sor_grid_copies;
     return 0;
   }
   if (!strcmp(name, "sor_fast_division")) {

@@ -62,7 +62,19 @@ struct nsk_ctx {
   int step_fused = 1;    // nsk_ns_step: 1 = three fused kernels around the Poisson loop, 0 = one launch per call site
   int poisson_rows = 0;  // rows per task chunk, 0 = automatic (NSK_POISSON_ROWS / nsk_set_option)
   int code3_steps_done = 0;  // complete time steps of the last nsk_bub_code3_step / _run call
+  // lexicographic SOR on the whole chip (bubble_sor_grid.hip): control words, progress words and tile order
+  int sor_grid = 1;       // 1 = grids beyond one workgroup's LDS are solved by tiles on the whole chip, 0 = by one workgroup
+  int sor_grid_rows = 0;  // tile height, 0 = default
+  int sor_grid_copies = 0;  // copies of the unknown in the ring, 0 = by the grid (testing)
+  unsigned *sor_grid_ctl = nullptr;
+  size_t sor_grid_words = 0, sor_grid_zero = 0;
+  int sor_grid_ti = 0, sor_grid_tj = 0;
 };
+
+// bubble_sor_grid.hip
+int nsk_sor_grid(nsk_ctx *ctx, int mode, double *a, const double *c1, const double *c2, const double *c3,
+                 double beta, double dx, double dy, int nx, int ny, int maxit, double maxError, int *d_sweeps,
+                 double *d_change);
 
 void nsk_set_error(const char *fmt, ...);
 

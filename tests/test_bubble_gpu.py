@@ -104,6 +104,56 @@ def test_grid_kernels(gpu, bo, nx, ny):
     assert same_bits(d["r"].get(), 0.5 * (r + ro))
 
 
+@pytest.mark.parametrize("nx,ny,rows,copies", [(70, 45, 0, 0), (129, 200, 0, 0), (129, 200, 8, 0), (200, 129, 16, 3),
+                                                (256, 256, 0, 0), (256, 256, 4, 5), (64, 300, 64, 4), (65, 33, 32, 0)])
+def test_sor_on_the_whole_chip(gpu, bo, nx, ny, rows, copies):
+    """Lexicographic SOR on grids beyond one workgroup's LDS: tiles of 64 x `rows` cells, a wavefront per
+    (tile, sweep), several sweeps in flight across the chip.  Pressure and density solves: sweep count,
+    last change and values (strict bit patterns) equal the serial loop of the oracle for stopping points
+    from the first sweep to the sweep limit, with more and with fewer copies of the unknown than sweeps
+    fit in flight, and equal the single-workgroup kernel."""
+    rng = np.random.default_rng(nx * 7 + ny + rows)
+    dx, dy = 1.0 / nx, 1.3 / ny
+    rt = rf(rng, nx + 2, ny + 2, 1.0)
+    t1 = rf(rng, nx + 2, ny + 2) * 30.0
+    ut, vt = rf(rng, nx + 1, ny + 2), rf(rng, nx + 2, ny + 1)
+    t1d, t2 = np.zeros_like(rt), np.zeros_like(rt)
+    bo.compute_sources(t1d, t2, rt, ut, vt, 0.00125, dx, dy, nx, ny)
+    p0 = rf(rng, nx + 2, ny + 2)
+    fx, fy, r0 = rf(rng, nx + 2, ny + 2), rf(rng, nx + 2, ny + 2), rf(rng, nx + 2, ny + 2, 1.0)
+    gpu.set_option("sor_grid_rows", rows)
+    gpu.set_option("sor_grid_copies", copies)
+    drt, dt1, dt2, dfx, dfy = Dev(rt), Dev(t1), Dev(t2), Dev(fx), Dev(fy)
+    try:
+        for maxit, tol in ((1, 0.0), (2, 0.0), (7, 0.0), (40, 0.0), (400, 5e-2), (400, 1e-3)):
+            p = p0.copy(order="F")
+            chr_ = C.c_double(0.0)
+            it = bo.lib.bub_solve_pressure(p.ctypes.data_as(C.c_void_p), t1.ctypes.data_as(C.c_void_p), t2.ctypes.data_as(C.c_void_p),
+                                           rt.ctypes.data_as(C.c_void_p), C.c_double(1.2), C.c_double(dx), C.c_double(dy), nx, ny, maxit,
+                                           C.c_double(tol), C.byref(chr_))
+            for grid in (1, 0):
+                if grid == 0 and (maxit > 7 or nx * ny > 30000):
+                    continue                      # the single-workgroup kernel takes milliseconds per sweep
+                gpu.set_option("sor_grid", grid)
+                dp = Dev(p0)
+                sw, ch = C.c_int(0), C.c_double(0.0)
+                gpu.bub_solve_pressure(dp.ptr, dt1.ptr, dt2.ptr, drt.ptr, 1.2, dx, dy, nx, ny, maxit, tol, C.byref(sw), C.byref(ch))
+                assert (sw.value, ch.value) == (it, chr_.value), (grid, maxit, tol)
+                assert strict_bits(dp.get(), p), (grid, maxit, tol)
+            gpu.set_option("sor_grid", 1)
+            r = r0.copy(order="F")
+            it = bo.construct_den(r, fx, fy, 1.2, maxit, tol, dx, dy, nx, ny)
+            dr = Dev(r0)
+            sw = C.c_int(0)
+            gpu.bub_construct_den(dr.ptr, dfx.ptr, dfy.ptr, 1.2, maxit, tol, dx, dy, nx, ny, C.byref(sw))
+            assert sw.value == it, (maxit, tol)
+            assert strict_bits(dr.get(), r), (maxit, tol)
+    finally:
+        gpu.set_option("sor_grid", 1)
+        gpu.set_option("sor_grid_rows", 0)
+        gpu.set_option("sor_grid_copies", 0)
+
+
 def test_set_density(gpu, bo):
     nx, ny = 61, 40
     x, y = cell_centres(nx, 1.0 / nx), cell_centres(ny, 1.0 / ny)
