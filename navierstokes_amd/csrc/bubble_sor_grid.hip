@@ -53,25 +53,26 @@ struct GridSor {
   int P;                       // sweeps start in batches of R, a batch every P >= R rounds (see nsk_sor_grid)
 };
 
+// Debug builds (-DNSK_SOR_GRID_TRACE): every workgroup sums the time its tasks spend in each phase (100 MHz
+// clock) into the words behind the tile order; tools/trace_sor_grid.py prints the averages.
+#ifdef NSK_SOR_GRID_TRACE
+#define TRACE_MARK(i)                                  \
+  do {                                                 \
+    const u64 now_ = wall_clock64();                   \
+    if (lane == 0) tr[i] += now_ - tlast;              \
+    tlast = now_;                                      \
+  } while (0)
+#else
+#define TRACE_MARK(i) \
+  do {                \
+  } while (0)
+#endif
+
 #define RLX __ATOMIC_RELAXED
 #define AGENT __HIP_MEMORY_SCOPE_AGENT
 
 __device__ __forceinline__ unsigned ld_word(unsigned *p) { return __hip_atomic_load(p, RLX, AGENT); }
 __device__ __forceinline__ void st_word(unsigned *p, unsigned v) { __hip_atomic_store(p, v, RLX, AGENT); }
-
-// Waits until *w >= v.  False: the solve has ended (a final sweep was found, or an error).
-__device__ __forceinline__ bool wait_ge(unsigned *w, unsigned v, unsigned *ctrl, unsigned code) {
-  for (unsigned spins = 0;; spins++) {
-    if (ld_word(w) >= v) return true;
-    if (ld_word(ctrl + C_FINAL) != 0) return false;
-    if (spins > SPIN_LIMIT) {
-      st_word(ctrl + C_ERR, code);
-      st_word(ctrl + C_FINAL, FINAL_ERROR);
-      return false;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-}
 
 // value of the lane below (lane 0 receives 0): v_mov_b32 with the DPP control wave_shr:1
 __device__ __forceinline__ double from_lane_below(double x) {
@@ -90,7 +91,19 @@ __global__ void __launch_bounds__(64) k_sor_grid(GridSor G) {
   const int tile_elems = (G.BJ + 2) * LDT;
   double *a = lds, *k1 = a + tile_elems, *k2 = k1 + tile_elems, *rt = k2 + tile_elems;
   const double beta = G.beta, dx = G.dx, dy = G.dy;
+#ifdef NSK_SOR_GRID_TRACE
+  u64 tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+  struct Flush {
+    u64 *tr, *out;
+    int lane;
+    __device__ ~Flush() {
+      if (lane == 0)
+        for (int i = 0; i < 8; i++) out[i] = tr[i];
+    }
+  } flush{tr, reinterpret_cast<u64 *>(const_cast<int *>(G.tiles) + G.NT + (G.NT & 1)) + 8 * blockIdx.x, lane};
+#endif
   for (;;) {
+    TRACE_MARK(0);  // between tasks: the counter, skipped task numbers
     unsigned n = 0;
     if (lane == 0) n = __hip_atomic_fetch_add(G.ctrl + C_NEXT, 1u, RLX, AGENT);
     n = __builtin_amdgcn_readfirstlane(n);
@@ -104,100 +117,193 @@ __global__ void __launch_bounds__(64) k_sor_grid(GridSor G) {
     if (m >= G.R) continue;  // the gap between two batches of sweeps
     const int k = batch * G.R + 1 + m;
     if (k > G.maxit) continue;
-    // ---- what this task waits for ---------------------------------------------------------------
-    const unsigned uk = (unsigned)k;
-    bool go = true;
-    if (I == 0 && J == 0 && k > G.R) go = wait_ge(G.ctrl + C_JUDGED, uk - (unsigned)G.R, G.ctrl, 1);
-    if (go && I > 0) go = wait_ge(G.prog + (J * G.TI + I - 1), uk, G.ctrl, 2);
-    if (go && J > 0) go = wait_ge(G.prog + ((J - 1) * G.TI + I), uk, G.ctrl, 3);
-    if (go && I + 1 < G.TI) go = wait_ge(G.prog + (J * G.TI + I + 1), uk - 1, G.ctrl, 4);
-    if (go && J + 1 < G.TJ) go = wait_ge(G.prog + ((J + 1) * G.TI + I), uk - 1, G.ctrl, 5);
-    if (go && I + 1 == G.TI && J + 1 == G.TJ) go = wait_ge(G.prog + (J * G.TI + I), uk - 1, G.ctrl, 6);
-    if (!go) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // ---- the tile with its halo into LDS --------------------------------------------------------
     const int w = min(TW, G.nx - TW * I), h = min(G.BJ, G.ny - G.BJ * J);
-    const double *oldc = k == 1 ? G.a : G.ring + (size_t)((k - 1) % G.R) * ncell;
-    double *newc = G.ring + (size_t)(k % G.R) * ncell;
     // 0-based global index of tile element (c, rr), c = 0..w+1, rr = 0..h+1 (halo included)
     const size_t g00 = (size_t)(G.BJ * J) * ldg + (size_t)(TW * I);
+    constexpr int CH = 12;  // rows requested together, so that their latencies overlap
+    // ---- the coefficients of the tile (nobody writes them): requested before the waits ----------
+    // Straight-line code: rows past the tile's last row and lanes past its last column repeat the last
+    // one (the same value goes to the same place again).
+    const int cl = min(lane, w + 1);
+    for (int rr0 = 0; rr0 <= h + 1; rr0 += CH) {
+      double v1[CH], v2[CH], v3[CH];
+#pragma unroll
+      for (int u = 0; u < CH; u++) {
+        const size_t g = g00 + (size_t)min(rr0 + u, h + 1) * ldg + cl;
+        v1[u] = G.c1[g];
+        v2[u] = G.c2[g];
+        v3[u] = MODE == 0 ? G.c3[g] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < CH; u++) {
+        const int t = min(rr0 + u, h + 1) * LDT + cl;
+        if (MODE == 0) {
+          k1[t] = v1[u];
+          k2[t] = beta * v2[u];
+          rt[t] = v3[u];
+        } else {
+          k1[t] = dx * v1[u];
+          k2[t] = dy * v2[u];
+        }
+      }
+    }
+    if (w + 1 >= TW) {  // columns 64 and 65 of a full-width tile: a lane per row, two rounds of rows
+      const int c = TW + (lane & 1);
+      for (int rr0 = 0; rr0 <= h + 1; rr0 += TW / 2) {
+        const int rr = min(rr0 + (lane >> 1), h + 1);
+        const size_t g = g00 + (size_t)rr * ldg + c;
+        const int t = rr * LDT + c;
+        const double v1 = G.c1[g], v2 = G.c2[g], v3 = MODE == 0 ? G.c3[g] : 0.0;
+        if (MODE == 0) {
+          k1[t] = v1;
+          k2[t] = beta * v2;
+          rt[t] = v3;
+        } else {
+          k1[t] = dx * v1;
+          k2[t] = dy * v2;
+        }
+      }
+    }
+    TRACE_MARK(1);  // coefficients
+    // ---- what this task waits for ---------------------------------------------------------------
+    // One lane per word, all of them asked for together: lanes 0..5 hold the (word, value) pairs of this
+    // task, lane 6 watches the word that ends the solve.
+    const unsigned uk = (unsigned)k;
+    unsigned *word = G.ctrl + C_FINAL;
+    unsigned need = 0;  // lanes without a condition: satisfied by any value
+    if (lane == 0 && I == 0 && J == 0 && k > G.R) word = G.ctrl + C_JUDGED, need = uk - (unsigned)G.R;
+    if (lane == 1 && I > 0) word = G.prog + (J * G.TI + I - 1), need = uk;
+    if (lane == 2 && J > 0) word = G.prog + ((J - 1) * G.TI + I), need = uk;
+    if (lane == 3 && I + 1 < G.TI) word = G.prog + (J * G.TI + I + 1), need = uk - 1;
+    if (lane == 4 && J + 1 < G.TJ) word = G.prog + ((J + 1) * G.TI + I), need = uk - 1;
+    if (lane == 5 && I + 1 == G.TI && J + 1 == G.TJ) word = G.prog + (J * G.TI + I), need = uk - 1;
+    bool go = false;
+    for (unsigned spins = 0;; spins++) {
+      const unsigned x = ld_word(word);
+      if (__any(lane == 6 && x != 0)) break;  // a final sweep was found, or an error
+      if (__all(x >= need)) {
+        go = true;
+        break;
+      }
+      if (spins > SPIN_LIMIT) {
+        if (lane == 0) {
+          st_word(G.ctrl + C_ERR, (unsigned)n);
+          st_word(G.ctrl + C_FINAL, FINAL_ERROR);
+        }
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!go) return;
+    TRACE_MARK(2);  // waits
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- the unknown on the tile and its halo ---------------------------------------------------
+    const double *oldc = k == 1 ? G.a : G.ring + (size_t)((k - 1) % G.R) * ncell;
+    double *newc = G.ring + (size_t)(k % G.R) * ncell;
     // Element (c, rr): ghost cells never change, the caller's array holds them; left / lower neighbours
     // come from this sweep's copy, everything else from the previous sweep's.
-    auto fetch = [&](int c, int rr, double &va, double &v1, double &v2, double &v3) {
+    auto fetch = [&](int c, int rr) -> double {
       const size_t g = g00 + (size_t)rr * ldg + c;
       const bool side = c == 0 || c == w + 1, ends = rr == 0 || rr == h + 1;
-      const double *src = oldc;
-      if (c == 0) src = I == 0 ? G.a : newc;
-      else if (c == w + 1) src = I + 1 == G.TI ? G.a : oldc;
-      else if (rr == 0) src = J == 0 ? G.a : newc;
-      else if (rr == h + 1) src = J + 1 == G.TJ ? G.a : oldc;
-      va = (side && ends) ? 0.0 : src[g];  // the corners are not part of the stencil
-      v1 = G.c1[g];
-      v2 = G.c2[g];
-      v3 = MODE == 0 ? G.c3[g] : 0.0;
+      const double *west_src = I == 0 ? G.a : newc, *east_src = I + 1 == G.TI ? G.a : oldc;
+      const double *south_src = J == 0 ? G.a : newc, *north_src = J + 1 == G.TJ ? G.a : oldc;
+      const double *src = c == 0 ? west_src : c == w + 1 ? east_src : rr == 0 ? south_src : rr == h + 1 ? north_src : oldc;
+      const double v = src[g];
+      return (side && ends) ? 0.0 : v;  // the corners are not part of the stencil
     };
-    auto keep = [&](int c, int rr, double va, double v1, double v2, double v3) {
-      const int t = rr * LDT + c;
-      a[t] = va;
-      if (MODE == 0) {
-        k1[t] = v1;
-        k2[t] = beta * v2;
-        rt[t] = v3;
-      } else {
-        k1[t] = dx * v1;
-        k2[t] = dy * v2;
-      }
-    };
-    constexpr int CH = 8;  // rows requested together, so that their latencies overlap
-    for (int rr0 = 0; rr0 <= h + 1; rr0 += CH) {
-      double va[CH], v1[CH], v2[CH], v3[CH];
+    constexpr int CHA = 34;  // a tile of 32 rows and its halo in one go
+    for (int rr0 = 0; rr0 <= h + 1; rr0 += CHA) {
+      double va[CHA];
 #pragma unroll
-      for (int u = 0; u < CH; u++)
-        if (rr0 + u <= h + 1 && lane <= w + 1) fetch(lane, rr0 + u, va[u], v1[u], v2[u], v3[u]);
+      for (int u = 0; u < CHA; u++) va[u] = fetch(cl, min(rr0 + u, h + 1));
 #pragma unroll
-      for (int u = 0; u < CH; u++)
-        if (rr0 + u <= h + 1 && lane <= w + 1) keep(lane, rr0 + u, va[u], v1[u], v2[u], v3[u]);
+      for (int u = 0; u < CHA; u++) a[min(rr0 + u, h + 1) * LDT + cl] = va[u];
     }
-    // columns 64 and 65 of a full-width tile: a lane per row
-    for (int c = TW; c <= w + 1; c++)
-      for (int rr = lane; rr <= h + 1; rr += TW) {
-        double va, v1, v2, v3;
-        fetch(c, rr, va, v1, v2, v3);
-        keep(c, rr, va, v1, v2, v3);
+    if (w + 1 >= TW) {
+      const int c = TW + (lane & 1);
+      for (int rr0 = 0; rr0 <= h + 1; rr0 += TW / 2) {
+        const int rr = min(rr0 + (lane >> 1), h + 1);
+        a[rr * LDT + c] = fetch(c, rr);
       }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    TRACE_MARK(3);  // acquire + the unknown
     // ---- the sweep over the tile: lane = column, columns one step apart -------------------------
+    // What a cell needs from the previous sweep (its own value, the values to the right and above) and
+    // its coefficients are read one step ahead; the values of this sweep arrive in registers (the left
+    // one from the lane below, the lower one is the lane's own previous result), so nothing that a step
+    // waits for goes through memory.  A lane overwrites a cell one or two steps after its neighbours
+    // have read the old value (cell (c, r) is written at step c + r; its old value is read at steps
+    // c + r - 2 and c + r - 1).
+    // The step is straight-line code (a lane outside its column's rows works on a clamped cell and keeps
+    // nothing), so that the reads and quotients prepared for the next step fill the waits of this step's
+    // chain of dependent operations.
     const int ci = lane;
+    struct Cell {
+      int q;
+      double old, e, n, dw, ds, s1, s2, halo_w, halo_s;
+    };
+    auto prepare = [&](int s) -> Cell {
+      Cell c;
+      const int r = min(max(s - ci, 0), h - 1);
+      const int q = (r + 1) * LDT + min(ci, w - 1) + 1;
+      c.q = q;
+      c.old = a[q];
+      const double east = a[q + 1], north = a[q + LDT];
+      c.halo_w = a[q - 1];     // used by lane 0 only
+      c.halo_s = a[q - LDT];   // used in row 0 only
+      if (MODE == 0) {
+        const double rc = rt[q], re = rt[q + 1], rw = rt[q - 1], rn = rt[q + LDT], rs = rt[q - LDT];
+        c.e = east / (dx * (re + rc));
+        c.n = north / (dy * (rn + rc));
+        c.dw = dx * (rw + rc);
+        c.ds = dy * (rs + rc);
+        c.s1 = k1[q];
+        c.s2 = k2[q];
+      } else {
+        c.e = east;
+        c.n = north;
+        c.dw = k1[q - 1];
+        c.ds = k2[q - LDT];
+        c.s1 = k1[q];
+        c.s2 = k2[q];
+      }
+      return c;
+    };
     double prev = 0.0;  // the value this lane produced in the previous step
     u64 mymax = 0;
     const int steps = w + h - 1;
+    Cell nxt = prepare(0);
     for (int s = 0; s < steps; s++) {
-      const int r = s - ci;
+      const Cell c = nxt;
       const double from_west = from_lane_below(prev);
-      if (ci < w && r >= 0 && r < h) {
-        const int q = (r + 1) * LDT + ci + 1;
-        const double old = a[q], east = a[q + 1], north = a[q + LDT];
-        const double west = ci == 0 ? a[q - 1] : from_west;
-        const double south = r == 0 ? a[q - LDT] : prev;
-        double nw;
-        if (MODE == 0) {
-          const double rc = rt[q], re = rt[q + 1], rw = rt[q - 1], rn = rt[q + LDT], rs = rt[q - LDT];
-          const double ex = east / (dx * (re + rc)) + west / (dx * (rw + rc));
-          const double ey = north / (dy * (rn + rc)) + south / (dy * (rs + rc));
-          nw = (1.0 - beta) * old + k2[q] * ((1.0 / dx) * ex + (1.0 / dy) * ey - k1[q]);
-        } else {
-          nw = (1.0 - beta) * old + beta * (0.25 * (east + west + north + south + k1[q - 1] - k1[q] + k2[q - LDT] - k2[q]));
-        }
-        a[q] = nw;
-        prev = nw;
-        const u64 b = (u64)__double_as_longlong(fabs(old - nw));
-        mymax = b > mymax ? b : mymax;
+      nxt = prepare(s + 1);
+      const int r = s - ci;
+      const bool act = ci < w && r >= 0 && r < h;
+      const double west = ci == 0 ? c.halo_w : from_west;
+      const double south = r == 0 ? c.halo_s : prev;
+      double nw;
+      if (MODE == 0) {
+        const double ex = c.e + west / c.dw;
+        const double ey = c.n + south / c.ds;
+        nw = (1.0 - beta) * c.old + c.s2 * ((1.0 / dx) * ex + (1.0 / dy) * ey - c.s1);
+      } else {
+        nw = (1.0 - beta) * c.old + beta * (0.25 * (c.e + west + c.n + south + c.dw - c.s1 + c.ds - c.s2));
       }
+      if (act) a[c.q] = nw;
+      prev = act ? nw : prev;
+      const u64 b = (u64)__double_as_longlong(fabs(c.old - nw));
+      mymax = (act && b > mymax) ? b : mymax;
+      // (for the compiler: the LDS accesses of a step stay in that step -- lanes read what other lanes write)
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+    TRACE_MARK(4);  // the sweep
+#ifdef NSK_SOR_GRID_TRACE
+    if (lane == 0) tr[7] += 1;
+#endif
     // ---- the tile's new values, write-through, then its progress word ---------------------------
     for (int rr = 1; rr <= h; rr++)
       if (lane < w) {
@@ -219,6 +325,7 @@ __global__ void __launch_bounds__(64) k_sor_grid(GridSor G) {
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every lane's stores and the maximum have left
+    TRACE_MARK(5);  // stores, maximum, drain
     if (lane == 0) st_word(G.prog + (J * G.TI + I), uk);
     if (last_tile && lane == 0) {
       // The upper right tile is the last task of its sweep, and every other task of the sweep lies on a
@@ -236,6 +343,7 @@ __global__ void __launch_bounds__(64) k_sor_grid(GridSor G) {
       }
     }
     __builtin_amdgcn_wave_barrier();
+    TRACE_MARK(6);  // flag, judgement
   }
 }
 
@@ -303,7 +411,11 @@ int nsk_sor_grid(nsk_ctx *ctx, int mode, double *a, const double *c1, const doub
   G.total = (int)(rounds * G.NT);
   // control block: [ctrl | prog | smax] zeroed per call, then the tile order
   const size_t zero_words = ((size_t)C_WORDS + G.NT + 2 * ((size_t)R + 1) + 3) / 4 * 4;
+#ifdef NSK_SOR_GRID_TRACE
+  const size_t need = zero_words + (size_t)G.NT + 2 + 16 * 4096;
+#else
   const size_t need = zero_words + (size_t)G.NT;
+#endif
   if (ctx->sor_grid_words < need) {
     if (ctx->sor_grid_ctl) NSK_HIP(hipFree(ctx->sor_grid_ctl));
     ctx->sor_grid_ctl = nullptr;
@@ -354,3 +466,15 @@ int nsk_sor_grid(nsk_ctx *ctx, int mode, double *a, const double *c1, const doub
   NSK_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef NSK_SOR_GRID_TRACE
+// debug builds only: the per-workgroup phase sums of the last solve (8 words per workgroup)
+extern "C" int nsk_sor_grid_trace(nsk_ctx *ctx, unsigned long long *out, int max_blocks) {
+  NSK_CTX(ctx);
+  NSK_HIP(hipStreamSynchronize(ctx->stream));
+  const size_t nt = (size_t)ctx->sor_grid_ti * ctx->sor_grid_tj;
+  const unsigned *base = ctx->sor_grid_ctl + ctx->sor_grid_zero + nt + (nt & 1);
+  NSK_HIP(hipMemcpy(out, base, (size_t)max_blocks * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return 0;
+}
+#endif

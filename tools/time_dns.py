@@ -64,11 +64,29 @@ for name, fn, arrays in K:
     arr = arrays / 8 if "it)" in name else arrays
     gbs = arr * cells * 8 / per / 1e3 if arr else float("nan")
     print(f"{name:28s} {per:10.1f} {arr:7.1f} {gbs:9.0f}")
-# lexicographic SOR in one workgroup (the reference's order) for scale
-t0 = time.perf_counter()
-k.bub_solve_pressure(S.p.ptr, S.tmp1.ptr, S.tmp2.ptr, S.rhot.ptr, q.beta, q.dx, q.dy, nx, ny, 4, 0.0, C.byref(sw), None)
+# lexicographic SOR (the reference's order): tiles on the whole chip with several sweeps in flight, against one
+# workgroup that sweeps the anti-diagonals one sweep at a time
+def sor(sweeps):
+    k.bub_solve_pressure(S.p.ptr, S.tmp1.ptr, S.tmp2.ptr, S.rhot.ptr, q.beta, q.dx, q.dy, nx, ny, sweeps, 0.0, C.byref(sw), None)
+
+
+for rows in (16, 32, 64):
+    k.set_option("sor_grid_rows", rows)
+    sor(2)                                            # the ring of copies is allocated on the first call
+    for sweeps in (4, 50, 200):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sor(sweeps)
+        dt_ = time.perf_counter() - t0
+        print(f"{'lexicographic SOR sweep':28s} {dt_/sweeps*1e6:10.1f}   (tiles of 64 x {rows} on the chip, {sweeps} sweeps in one solve: {dt_*1e3:.2f} ms)")
+k.set_option("sor_grid_rows", 0)
+k.set_option("sor_grid", 0)
+sor(1)
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+sor(4)
 print(f"{'lexicographic SOR sweep':28s} {(time.perf_counter()-t0)/4*1e6:10.1f}   (one workgroup, anti-diagonal wavefront)")
+k.set_option("sor_grid", 1)
 if a.cpu:
     from oracle.bubble_oracle import OracleDNS
     o = OracleDNS(q)
