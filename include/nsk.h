@@ -51,6 +51,8 @@ const char *nsk_version(void);
 #define NSK_ERR_FRONT_CAPACITY 3 /* the regridded front needs more than `cap` points: the place where
                                   * scripts/code3_fun.jl:462-465 resizes its vectors; see
                                   * nsk_bub_code3_run_status for how a caller continues */
+#define NSK_ERR_TIMEOUT 5        /* nsk_slabs_*: a host-side wait behind an exchange or an all-reduce ran into
+                                  * its deadline (nsk_slabs_set_option "deadline_ms", "first_contact_ms") */
 #define NSK_ERR_FRONT_OUTSIDE 4  /* a front point left the box [0,Lx] x [0,Ly]: the reference prints a
                                   * message (scripts/code3_fun.jl:186-188) and its next array access
                                   * by that point throws; the state is not to be used */
@@ -328,7 +330,9 @@ int nsk_slabs_poisson(nsk_slabs *g, int *iters_out, double *err_hist, int *iter_
 int nsk_slabs_init_flow(nsk_slabs *g, const double *Vprof_host);
 /* One pass of the time-loop body NavierStokes.jl:79-100 on the slab-decomposed grid (outputs as
  * nsk_ns_step).  The back-trace of advect! must stay inside the halo: reach = max|Vy| dt/dy + 2 >
- * halo - 1 is an error, not a wrong answer.  Synchronous. */
+ * halo - 1 is an error, not a wrong answer: the bound is tested on entry (velocities as they are) and
+ * again after the projection; after the second kind of failure the windows hold a half-finished step and
+ * the group has to be set up again with a wider halo.  Synchronous. */
 int nsk_slabs_step(nsk_slabs *g, int *iters_out, double *err_hist, int *iter_hist, int hist_cap,
                    int *nhist_out);
 int nsk_slabs_sync(nsk_slabs *g);
@@ -339,7 +343,14 @@ int nsk_slabs_info(nsk_slabs *g, int *world, int *nlocal, int *transport, int *e
 /* Switches with no effect on any result: "edges_first" (default 1) -- the last launch of every
  * block of Poisson passes produces the rows the neighbours wait for first
  * (nsk_ns_poisson_iters_edges_first), so that the halo exchange runs beside the rest of that
- * launch; 0 = whole window, then the exchange. */
+ * launch; 0 = whole window, then the exchange.
+ * "deadline_ms" (default 60000), "first_contact_ms" (default 180000; applies until the first wait behind
+ * an exchange or an all-reduce has succeeded): every host-side wait of the group (nsk_slabs_sync,
+ * nsk_slabs_residual and the calls built on them) polls its stream and gives up with NSK_ERR_TIMEOUT and
+ * a description (slab, device, neighbours, bytes, transport, schedule, exchanges queued, whether the last
+ * one completed) after that many milliseconds instead of waiting for good; 0 = wait for good.  The group
+ * is not usable after a timeout.  "test_stall_ms": the next exchange is held back on the device for that
+ * long (a bounded idle kernel; for the test of the deadline). */
 int nsk_slabs_set_option(nsk_slabs *g, const char *name, int value);
 
 /* ---- bubble / drop solvers: scripts/DNS.jl (= scripts/code1.m) and scripts/code3_fun.jl ---

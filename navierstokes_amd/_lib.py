@@ -23,7 +23,7 @@ class NskError(RuntimeError):
         self.code = code
 
 
-ERR_HIP, ERR_ARGUMENT, ERR_FRONT_CAPACITY, ERR_FRONT_OUTSIDE = 1, 2, 3, 4
+ERR_HIP, ERR_ARGUMENT, ERR_FRONT_CAPACITY, ERR_FRONT_OUTSIDE, ERR_TIMEOUT = 1, 2, 3, 4, 5
 
 
 class CNSParams(C.Structure):
@@ -251,8 +251,9 @@ class Slabs:
         self.handle, self.nlocal = h, len(devices)
 
     def call(self, name, *args):
-        if getattr(self.lib, name)(self.handle, *args) != 0:
-            raise NskError(f"{name}: {self.lib.nsk_last_error().decode()}")
+        rc = getattr(self.lib, name)(self.handle, *args)
+        if rc != 0:
+            raise NskError(f"{name}: {self.lib.nsk_last_error().decode()}", rc)
 
     def window(self, local=0) -> dict:
         v = [C.c_int(0) for _ in range(7)]

@@ -20,7 +20,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 #include "nsk_internal.h"
@@ -139,6 +141,14 @@ struct nsk_slabs {
   // Poisson blocks end with the rows to be sent produced first (nsk_ns_poisson_iters_edges_first),
   // so that they travel while the rest of the window is still being computed
   bool edges_first = true;
+  // Host-side waits are loops over hipStreamQuery with a deadline: a transfer that never completes (a
+  // mismatched send / receive on the first run on a real node, a peer that died) ends the call with
+  // NSK_ERR_TIMEOUT and a description instead of hanging.  first_contact_ms applies until the first
+  // wait behind an exchange or an all-reduce has succeeded, deadline_ms afterwards; 0 = wait for good.
+  int first_contact_ms = 180000, deadline_ms = 60000;
+  bool contact_made = false;
+  int test_stall_ms = 0;  // (testing) the next exchange is held back on the device for this long
+  size_t last_exchange_bytes = 0;
 };
 
 namespace {
@@ -176,6 +186,45 @@ inline XField xfield(const nsk_slabs *g, int id) {
   return {id, nx, false};
 }
 
+// A kernel that does nothing for `ms` milliseconds (100 MHz clock) and then ends: the stand-in for a
+// transfer that does not complete, used by the deadline test.  Bounded, so the stream always drains.
+__global__ void k_stall(long long ticks) {
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+// Waits for `st` (of slab `s`) with the group's deadline; see nsk_slabs::deadline_ms.
+int wait_stream(nsk_slabs *g, Slab &s, hipStream_t st, const char *what) {
+  const int limit = g->contact_made ? g->deadline_ms : g->first_contact_ms;
+  NSK_HIP(hipSetDevice(s.device));
+  if (limit <= 0) {
+    NSK_HIP(hipStreamSynchronize(st));
+    return 0;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; spins++) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotReady) {
+      nsk_set_error("%s: hipStreamQuery failed: %s", what, hipGetErrorString(e));
+      return NSK_ERR_HIP;
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms > limit) {
+      const bool last_done = s.ev_comm && hipEventQuery(s.ev_comm) == hipSuccess;
+      nsk_set_error("%s: no completion within %d ms on slab %d of %d (device %d, neighbours %d and %d): %d exchanges "
+                    "queued so far, the last one (%zu bytes per neighbour and direction, transport %s, %s schedule) has "
+                    "%s on this slab; the group is not usable after this",
+                    what, limit, s.rank, g->world, s.device, s.rank > 0 ? s.rank - 1 : -1,
+                    s.rank < g->world - 1 ? s.rank + 1 : -1, g->exchanges, g->last_exchange_bytes,
+                    g->transport == TRANSPORT_RCCL ? "RCCL" : "device copies", g->edges_first ? "edges-first" : "plain",
+                    last_done ? "completed" : "NOT completed");
+      return NSK_ERR_TIMEOUT;
+    }
+    if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
 // Refresh `h` halo rows per interior side of the listed fields on every local slab.  The rows to
 // be sent are final when the work queued so far on the slab's stream is done -- or, after
 // nsk_ns_poisson_iters_edges_first, on its edge stream (from_edge).
@@ -188,6 +237,17 @@ int exchange_list(nsk_slabs *g, const XField *xf, int nf, int h, bool from_edge 
   for (Slab &s : g->slabs) {  // transfers start when the rows to be sent are final
     NSK_HIP(hipSetDevice(s.device));
     NSK_HIP(hipEventRecord(s.ev_done, from_edge ? s.edge_stream : s.ctx->stream));
+  }
+  g->last_exchange_bytes = 0;
+  for (int f = 0; f < nf; f++) g->last_exchange_bytes += (size_t)(xf[f].faces ? h + 1 : h) * xf[f].ld * sizeof(double);
+  if (g->test_stall_ms > 0) {
+    for (Slab &s : g->slabs) {
+      NSK_HIP(hipSetDevice(s.device));
+      if (!from_edge) NSK_HIP(hipStreamWaitEvent(s.comm_stream, s.ev_done, 0));
+      k_stall<<<1, 64, 0, xstream(s)>>>((long long)g->test_stall_ms * 100000);
+      NSK_LAUNCH_CHECK();
+    }
+    g->test_stall_ms = 0;
   }
   if (g->transport == TRANSPORT_RCCL) {
     const Rccl *R = rccl();
@@ -290,10 +350,9 @@ int allreduce_max(nsk_slabs *g, unsigned long long *m) {
   Slab &s0 = g->slabs[0];
   NSK_HIP(hipSetDevice(s0.device));
   NSK_HIP(hipMemcpyAsync(g->red_host + 1, s0.red, sizeof *m, hipMemcpyDeviceToHost, s0.comm_stream));
-  for (Slab &s : g->slabs) {
-    NSK_HIP(hipSetDevice(s.device));
-    NSK_HIP(hipStreamSynchronize(s.comm_stream));
-  }
+  for (Slab &s : g->slabs)
+    if (int rc = wait_stream(g, s, s.comm_stream, "all-reduce of the residual")) return rc;
+  g->contact_made = g->contact_made || g->exchanges > 0;
   *m = g->red_host[1];
   return 0;
 }
@@ -539,11 +598,11 @@ extern "C" int nsk_slabs_exchange(nsk_slabs *g, int field_mask) {
 extern "C" int nsk_slabs_sync(nsk_slabs *g) {
   NSK_GROUP(g, 0);
   for (Slab &s : g->slabs) {
-    NSK_HIP(hipSetDevice(s.device));
-    NSK_HIP(hipStreamSynchronize(s.comm_stream));
-    NSK_HIP(hipStreamSynchronize(s.edge_stream));
-    NSK_HIP(hipStreamSynchronize(s.ctx->stream));
+    if (int rc = wait_stream(g, s, s.comm_stream, "nsk_slabs_sync (communication stream)")) return rc;
+    if (int rc = wait_stream(g, s, s.edge_stream, "nsk_slabs_sync (edge stream)")) return rc;
+    if (int rc = wait_stream(g, s, s.ctx->stream, "nsk_slabs_sync (kernel stream)")) return rc;
   }
+  g->contact_made = g->contact_made || g->exchanges > 0;
   return 0;
 }
 
@@ -575,6 +634,10 @@ extern "C" int nsk_slabs_residual(nsk_slabs *g, double *maxabs_out) {
   NSK_GROUP(g, 0);
   NSK_REQUIRE(maxabs_out != nullptr, "nsk_slabs_residual: maxabs_out is null");
   unsigned long long m = 0;
+  // the kernel streams are ordered behind the last exchange: wait for them here, where a transfer that
+  // never completes ends in an error (nsk_ns_residual itself waits for good)
+  for (Slab &s : g->slabs)
+    if (int rc = wait_stream(g, s, s.ctx->stream, "residual (kernel stream, behind the last exchange)")) return rc;
   for (Slab &s : g->slabs) {
     double v = 0.0;
     if (int rc = nsk_ns_residual(s.ctx, nullptr, s.Pr, s.divV, &s.prm, s.own_lo + 1, s.own_hi, &v)) return rc;
@@ -689,6 +752,31 @@ extern "C" int nsk_slabs_step(nsk_slabs *g, int *iters_out, double *err_hist, in
 #define NSK_EACH(call)      \
   for (Slab &s : g->slabs) \
     if (int rc_ = (call)) return rc_
+  // rows the back-trace of advect! may reach, |Vy| dt/dy + 1 below / above (one halo row is stale by then:
+  // predict_V! / correct_V! do not update a window's outermost row)
+  auto reach_of_advect = [&](double *reach) -> int {
+    unsigned long long m = 0;
+    for (Slab &s : g->slabs) {
+      double v = 0.0;
+      if (int rc = nsk_maxabs(s.ctx, s.Vy, (size_t)nx * (s.ny_win + 1), &v)) return rc;
+      unsigned long long b;
+      memcpy(&b, &v, sizeof b);
+      m = b > m ? b : m;
+    }
+    if (int rc = allreduce_max(g, &m)) return rc;
+    double vmax;
+    memcpy(&vmax, &m, sizeof vmax);
+    *reach = vmax * p->dt / p->dy + 2;
+    return 0;
+  };
+  if (g->world > 1) {
+    // with the velocities as they are on entry: a halo that is too narrow already is reported before
+    // anything has been changed
+    double reach = 0.0;
+    if (int rc = reach_of_advect(&reach)) return rc;
+    NSK_REQUIRE(reach <= g->halo - 1, "advect! would reach %.1f rows but only %d valid halo rows exist: raise the halo width "
+                "(nothing was changed)", reach, g->halo - 1);
+  }
   // :79-82
   NSK_EACH(nsk_update_tau(s.ctx, s.txx, s.tyy, s.txy, s.Vx, s.Vy, p->mu, p->dx, p->dy, nx, s.ny_win));
   NSK_EACH(nsk_predict_V(s.ctx, s.Vx, s.Vy, s.txx, s.tyy, s.txy, p->rho, p->g, p->dt, p->dx, p->dy, nx, s.ny_win));
@@ -704,22 +792,10 @@ extern "C" int nsk_slabs_step(nsk_slabs *g, int *iters_out, double *err_hist, in
                           p->dy, nx, s.ny_win, s.iy0));
   NSK_EACH(nsk_set_bc_Vel(s.ctx, s.Vx, s.Vy, s.Vprof, nx, s.ny_win, p->full_rows, s.iy0, nyg));
   if (g->world > 1) {
-    // rows the back-trace may reach: |Vy| dt/dy + 1 below / above; one halo row is already stale
-    // (predict_V! / correct_V! do not update a window's outermost row)
-    unsigned long long m = 0;
-    for (Slab &s : g->slabs) {
-      double v = 0.0;
-      if (int rc = nsk_maxabs(s.ctx, s.Vy, (size_t)nx * (s.ny_win + 1), &v)) return rc;
-      unsigned long long b;
-      memcpy(&b, &v, sizeof b);
-      m = b > m ? b : m;
-    }
-    if (int rc = allreduce_max(g, &m)) return rc;
-    double vmax;
-    memcpy(&vmax, &m, sizeof vmax);
-    const double reach = vmax * p->dt / p->dy + 2;
-    NSK_REQUIRE(reach <= g->halo - 1, "advect! reaches %.1f rows but only %d valid halo rows exist: raise the halo width",
-                reach, g->halo - 1);
+    double reach = 0.0;
+    if (int rc = reach_of_advect(&reach)) return rc;
+    NSK_REQUIRE(reach <= g->halo - 1, "advect! reaches %.1f rows but only %d valid halo rows exist: the windows hold a "
+                "half-finished time step; set the group up again with a wider halo", reach, g->halo - 1);
   }
   // :99-100
   NSK_EACH(nsk_copy(s.ctx, s.Vx_o, s.Vx, (size_t)(nx + 1) * s.ny_win));
@@ -737,6 +813,11 @@ extern "C" int nsk_slabs_set_option(nsk_slabs *g, const char *name, int value) {
   NSK_REQUIRE(name != nullptr, "nsk_slabs_set_option: name is null");
   if (!strcmp(name, "edges_first")) {
     g->edges_first = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "deadline_ms") || !strcmp(name, "first_contact_ms") || !strcmp(name, "test_stall_ms")) {
+    NSK_REQUIRE(value >= 0, "%s: %d", name, value);
+    (name[0] == 'd' ? g->deadline_ms : name[0] == 'f' ? g->first_contact_ms : g->test_stall_ms) = value;
     return 0;
   }
   nsk_set_error("nsk_slabs_set_option: unknown option '%s'", name);

@@ -203,6 +203,47 @@ def test_slab_time_step_rejects_a_halo_the_back_trace_would_leave(gpu):
             g.close()
 
 
+@pytest.mark.parametrize("edges_first", [1, 0])
+def test_a_transfer_that_does_not_complete_ends_in_an_error(gpu, oracle, edges_first):
+    """The host-side waits of a group have a deadline (first_contact_ms until the first exchange has been
+    waited for successfully, deadline_ms afterwards).  An exchange held back on the device for 1.5 s (a
+    bounded idle kernel where the transfer is queued) against a deadline of 0.3 s: the residual returns
+    NSK_ERR_TIMEOUT within the deadline and says which slab waited for what; nothing was aborted on the
+    device, so once the idle kernel has ended the same group delivers the right values."""
+    import time
+    world, ny_loc, halo, nx = 3, 40, 8, 70
+    nyg = world * ny_loc
+    p = ns_params("NavierStokes", nx=nx, ny=nyg)
+    Pr0, dP0, dv = fields(np.random.default_rng(5), nx, nyg)
+    g = make_group(p, world, ny_loc, halo)
+    try:
+        g.set_option("edges_first", edges_first)
+        g.set_option("first_contact_ms", 300)
+        g.set_option("deadline_ms", 300)
+        load(g, Pr0, dP0, dv)
+        g.set_option("test_stall_ms", 1500)
+        t0 = time.perf_counter()
+        g.poisson_iters(halo)                       # queues the passes and the (held back) exchange
+        with pytest.raises(_lib.NskError, match="no completion within 300 ms on slab .* of 3 .*1 exchanges queued") as e:
+            g.residual()
+        waited = time.perf_counter() - t0
+        assert e.value.code == _lib.ERR_TIMEOUT and 0.25 < waited < 1.2, waited
+        assert "device copies" in str(e.value) and ("edges-first" if edges_first else "plain") in str(e.value)
+        time.sleep(1.5)                             # the idle kernel ends by itself
+        g.set_option("deadline_ms", 20000)
+        g.set_option("first_contact_ms", 20000)
+        m = g.residual()
+        Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
+        oracle_passes(oracle, p, Pr, dP, dv, halo)
+        gPr, gdP = gathered(g, nx, nyg)
+        assert same_bits(gPr, Pr) and same_bits(gdP, dP)
+        Rp = np.zeros((nx - 2, nyg - 2), order="F")
+        oracle.compute_res(Rp, Pr, dv, p.rho, p.dt, p.dx, p.dy)
+        assert m == oracle.maxabs(Rp)
+    finally:
+        g.close()
+
+
 def test_rccl_transport_on_one_slab(gpu, oracle):
     """RCCL path as far as one GPU can take it: library loaded at run time, unique id, communicator of
     one rank, ncclAllReduce(max) inside the residual, and ncclSend/ncclRecv of row blocks to itself on
