@@ -17,16 +17,27 @@ travel over RCCL (navierstokes_amd/dist.py).  Prints ONE JSON line on rank 0.
 
 The `roofline` block: `achieved`/`frac` price the ALGORITHMIC bytes (40 B per cell and pass, K
 passes per launch) against the HBM peak -- with K passes per sweep over the fields this exceeds 1
-by design; `hbm_frac` prices the bytes the HBM counters saw per launch, `valu_frac` the issue
-cycles of the vector ALU instructions the launch executed; `bound` names the larger of the two.
+by design.  The physical fractions: `fabric_frac` prices the bytes the L2 <-> fabric counters
+(FETCH_SIZE / WRITE_SIZE: requests that leave L2, Infinity-Cache hits included, so an upper bound
+on the DRAM bytes) saw per launch, `valu_frac` the issue cycles of the vector ALU instructions the
+launch executed, at the 2.4 GHz peak clock and (`valu_frac_sustained`) at the clock the part held
+in the counter run (SQ_BUSY_CYCLES); `frac_of_bound` is the larger of the two, `bound` its name.
+`launch_us` is the device time of the timed loop itself (events on the launch stream around it)
+divided by its passes / K: the residual checks and a remainder launch are in it, so it bounds the
+kernel's average duration from above and launch_us x launches <= ms_per_step.
+
+N > 1: the first exchange and all-reduce run under a watchdog (--first-contact-s): if they do not
+complete, every rank prints where it was (rank, device, peers, bytes, schedule) and exits non-zero.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import faulthandler
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -53,6 +64,36 @@ def poisson_counters(kernel: str, nx: int, ny_win: int):
     if not t or t.get("kernel_hash") != poisson_kernel_hash() or t.get("grid") != [nx, ny_win]:
         return None
     return t
+
+
+class Watchdog:
+    """Ends the process (exit status 3, never a re-exec) when a phase does not finish in time: a host-side
+    deadline for work whose waits sit inside libraries (the first RCCL exchange and all-reduce of a
+    multi-GPU run).  `describe` returns what to print."""
+
+    def __init__(self, seconds: float, describe):
+        self.seconds, self.describe = seconds, describe
+        self.timer = None
+
+    def _expired(self):
+        try:
+            sys.stderr.write(f"bench.py: no completion within {self.seconds:.0f} s -- {self.describe()}\n")
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            sys.stderr.flush()
+        finally:
+            os._exit(3)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            self.timer = threading.Timer(self.seconds, self._expired)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
 
 
 def cpu_baseline(p, seconds_target=15.0):
@@ -91,6 +132,11 @@ def cpu_baseline(p, seconds_target=15.0):
             "steps_per_s_at_nchk": 1.0 / (t_iter * p.nchk)}
 
 
+def group_k(group) -> int:
+    """Passes per launch the library chose for the slab group's windows."""
+    return group.get_option("poisson_k")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +156,8 @@ def main():
     ap.add_argument("--abi-slabs", action="store_true",
                     help="run the slabs through the C ABI (nsk_slabs_*: RCCL called from the library, one slab "
                          "per process) instead of the torch.distributed host path")
+    ap.add_argument("--first-contact-s", type=float, default=240.0,
+                    help="N>1: deadline for process-group set-up, the first exchange and the first all-reduce")
     ap.add_argument("--time-steps", type=int, default=5,
                     help="additionally run this many whole reference time steps from the IC (N=1)")
     a = ap.parse_args()
@@ -131,11 +179,23 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    where = {"phase": "process group set-up", "exchanges": 0}
+
+    def describe():
+        peers = [r for r in (rank - 1, rank + 1) if 0 <= r < world]
+        return (f"rank {rank} of {world} on cuda:{local} ({torch.cuda.get_device_name(local)}), backend {a.backend}, "
+                f"peers {peers}, phase: {where['phase']}, exchanges completed: {where['exchanges']}, "
+                f"{a.halo} halo rows = {a.halo * 2560 * 8} bytes per field, neighbour and direction, "
+                f"schedule {'abi-slabs' if a.abi_slabs else (a.schedule or 'edges')}")
+
     if world > 1:
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(a.backend)
+        with Watchdog(a.first_contact_s, describe):
+            if os.environ.get("NSK_BENCH_TEST_STALL") == str(rank):      # (test of the watchdog: this rank never arrives)
+                time.sleep(10 * a.first_contact_s)
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(a.backend)
 
     p1 = ns_params("NavierStokes_Re6", n=a.n)                   # one GPU's slab
     nx, ny_loc = p1.nx, p1.ny
@@ -153,7 +213,11 @@ def main():
         return t.to(dev)
     Pr, divV = rnd(), rnd()
     dP = torch.zeros((slab.ny_win, ld), dtype=torch.float64, device=dev)
-    exchange_rows((Pr, divV), slab)
+    with Watchdog(a.first_contact_s if world > 1 else 0, describe):
+        where["phase"] = "first halo exchange (Pr, divV)"
+        exchange_rows((Pr, divV), slab)
+        torch.cuda.synchronize()
+        where["exchanges"] = 1
     be = HipBackend(ctx, p, ld)
     sp = SlabPoisson(p, slab, be, Pr, dP, divV, schedule=a.schedule)
 
@@ -189,15 +253,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    with Watchdog(a.first_contact_s if world > 1 else 0, describe):
+        # first contact of the loop itself: one block of passes with its exchange, one all-reduced residual
+        where["phase"] = "first block of Poisson passes and its exchange"
+        if group is not None:
+            group.poisson_iters(max(a.halo, 1))
+        else:
+            sp.iterate(max(a.halo, 1))
+        torch.cuda.synchronize()
+        where["exchanges"] += 1
+        where["phase"] = "first all-reduce of the residual"
+        group.residual() if group is not None else sp.residual()
+        where["phase"] = "barrier after the first contact"
+        fence()
+    where["phase"] = "warm-up / timed loop"
     for _ in range(a.warmup):
         step()
     fence()
     sp.timing, ex0 = world > 1, sp.exchanges
+    # device time of the timed loop, on the stream the library launches on (torch's current stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     for _ in range(a.steps):
         err = step()
+    e1.record()
     fence()
     dt = time.perf_counter() - t0
+    gpu_s = e0.elapsed_time(e1) * 1e-3
     exposed, n_exch = sp.exposed_us(), sp.exchanges - ex0
     sp.timing = False
     if world > 1:
@@ -205,28 +288,29 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, exposed = float(tt[0].item()), float(tt[1].item())
 
-    # dominant kernel, timed on the stream it runs on: launches of K passes back to back
-    be.poisson_iters(Pr, dP, divV, slab, 16)       # (the library picks the passes per launch on its first call)
-    kpl = ctx.get_option("poisson_k")
-    nl = 64
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    be.poisson_iters(Pr, dP, divV, slab, kpl * 2)
-    torch.cuda.synchronize()
-    e0.record()
-    be.poisson_iters(Pr, dP, divV, slab, kpl * nl)
-    e1.record()
-    torch.cuda.synchronize()
-    t_launch = e0.elapsed_time(e1) * 1e-3 / nl
+    # dominant kernel: its launches of K passes make up the timed loop but for the residual checks and a
+    # remainder launch per block, so loop time / (passes / K) bounds its average duration from above
+    kpl = ctx.get_option("poisson_k") if group is None else group_k(group)
+    launches = a.steps * passes / kpl
+    t_launch = gpu_s / launches
     alg_bytes = 40.0 * nx * slab.ny_win * kpl
     achieved = alg_bytes / t_launch / 1e9
 
     kernel = f"k_poisson<{kpl}>"
     cnt = poisson_counters(kernel, nx, slab.ny_win)
-    traffic = hbm_frac = valu_frac = None
+    traffic = fabric_frac = valu_frac = valu_sus = clock_sus = None
     if cnt:
         traffic = cnt["read_bytes"] + cnt["write_bytes"]
-        hbm_frac = traffic / t_launch / (HBM_PEAK_GBS * 1e9)
+        fabric_frac = traffic / t_launch / (HBM_PEAK_GBS * 1e9)
         valu_frac = cnt["insts_valu"] * VALU_CYCLES_F64 / (SIMDS * t_launch * CLOCK_GHZ * 1e9)
+        if cnt.get("sq_busy_cycles"):
+            # SQ_BUSY_CYCLES sums over the 32 shader engines: / 32 = cycles one launch took in the counter run
+            cyc = cnt["sq_busy_cycles"] / 32.0
+            valu_sus = cnt["insts_valu"] * VALU_CYCLES_F64 / (SIMDS * cyc)
+            if cnt.get("launch_us"):
+                clock_sus = cyc / cnt["launch_us"] * 1e-3
+    fracs = {"fabric": fabric_frac or 0.0, "valu": max(valu_frac or 0.0, valu_sus or 0.0)}
+    bound = max(fracs, key=fracs.get)
 
     cells = nx * ny_loc * world
     t_iter = dt / (a.steps * passes)
@@ -244,20 +328,38 @@ def main():
         "t_eff_over_hbm_peak": teff / (HBM_PEAK_GBS * world),
         "time_steps_per_s_at_min_iters": 1.0 / (t_iter * p1.nchk),
         "last_err": err,
-        "roofline": {"bound": "valu" if (valu_frac or 0.0) > (hbm_frac or 0.0) else "hbm",
+        "roofline": {"bound": "hbm" if bound == "fabric" else "valu",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "hbm_frac": hbm_frac, "valu_frac": valu_frac,
-                     "kernel": kernel, "launch_us": t_launch * 1e6,
+                     "traffic_kind": "L2<->fabric bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE): Infinity-Cache hits "
+                                     "included, an upper bound on DRAM bytes",
+                     "fabric_frac": fabric_frac, "valu_frac": valu_frac, "valu_frac_sustained": valu_sus,
+                     "sustained_clock_ghz": clock_sus,
+                     "frac_of_bound": max(fracs.values()) if cnt else None,
+                     "kernel": kernel, "launch_us": t_launch * 1e6, "launches_per_step": passes / kpl,
+                     "launch_us_from": "events around the timed loop / (passes / K): residual checks and remainder "
+                                       "launches included",
                      "algorithmic_bytes_per_launch": alg_bytes, "passes_per_launch": kpl,
                      "note": "achieved/frac price algorithmic bytes (K passes per sweep: > 1 by design); "
-                             "hbm_frac = counter bytes / launch / 8 TB/s; valu_frac = SQ_INSTS_VALU x 4 cycles / "
-                             "(1024 SIMDs x launch cycles at 2.4 GHz); null = no counters for this kernel build"},
+                             "fabric_frac = counter bytes / launch / 8 TB/s; valu_frac = SQ_INSTS_VALU x 4 cycles / "
+                             "(1024 SIMDs x launch cycles at 2.4 GHz), valu_frac_sustained the same at the clock of the "
+                             "counter run (SQ_BUSY_CYCLES / 32 per launch); null = no counters for this kernel build"},
     }
     if world > 1:
         out["schedule"] = "abi-slabs (RCCL from the library)" if group is not None else sp.schedule
         out["exchanges_timed"] = n_exch
         out["comm_exposed_us_per_exchange"] = exposed
+        # who took part: one entry per rank, gathered from every rank
+        props = torch.cuda.get_device_properties(local)
+        mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": f"cuda:{local}",
+                "name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")),
+                "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES"), "pid": os.getpid()}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        out["world_size"] = dist.get_world_size()
+        out["backend"] = dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")
+        out["ranks"] = everyone
+        out["distinct_devices"] = len({(e["uuid"], e["pci_bus_id"], e["device"]) for e in everyone})
     if rank == 0 and world == 1 and a.time_steps > 0:
         from navierstokes_amd.ns import NavierStokes
         sim = NavierStokes(p1, device=f"cuda:{local}")

@@ -352,6 +352,9 @@ int nsk_slabs_info(nsk_slabs *g, int *world, int *nlocal, int *transport, int *e
  * is not usable after a timeout.  "test_stall_ms": the next exchange is held back on the device for that
  * long (a bounded idle kernel; for the test of the deadline). */
 int nsk_slabs_set_option(nsk_slabs *g, const char *name, int value);
+/* Reads a group switch back; any other name is an option of nsk_get_option, answered by the context of the
+ * first local slab (e.g. "poisson_k": passes per launch its windows run with). */
+int nsk_slabs_get_option(nsk_slabs *g, const char *name, int *value);
 
 /* ---- bubble / drop solvers: scripts/DNS.jl (= scripts/code1.m) and scripts/code3_fun.jl ---
  * Grid arrays are (nx+2) x (ny+2) with one ghost layer; u is (nx+1) x (ny+2), v is

@@ -253,6 +253,11 @@ rccl_self_exchange!(s::Slabs, rows) =
 "Switches without effect on results, e.g. \"edges_first\" (default 1)."
 set_option!(s::Slabs, name::String, v::Integer) =
     check(ccall((:nsk_slabs_set_option, lib), Cint, (Ptr{Cvoid}, Cstring, Cint), s.h, name, v))
+function get_option(s::Slabs, name::String)
+    v = Ref{Cint}(0)
+    check(ccall((:nsk_slabs_get_option, lib), Cint, (Ptr{Cvoid}, Cstring, Ptr{Cint}), s.h, name, v))
+    Int(v[])
+end
 function info(s::Slabs)
     v = [Ref{Cint}(0) for _ = 1:4]
     check(ccall((:nsk_slabs_info, lib), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}), s.h, v[1], v[2], v[3], v[4]))

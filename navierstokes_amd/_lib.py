@@ -145,6 +145,7 @@ _SLAB_SIGS = {
     "nsk_slabs_rccl_self_exchange": [_I],
     "nsk_slabs_info": [c_int_p] * 4,
     "nsk_slabs_set_option": [C.c_char_p, _I],
+    "nsk_slabs_get_option": [C.c_char_p, c_int_p],
 }
 
 _lib = None
@@ -305,6 +306,11 @@ class Slabs:
 
     def set_option(self, name: str, value: int) -> None:
         self.call("nsk_slabs_set_option", name.encode(), int(value))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        self.call("nsk_slabs_get_option", name.encode(), C.byref(v))
+        return v.value
 
     def info(self) -> dict:
         v = [C.c_int(0) for _ in range(4)]

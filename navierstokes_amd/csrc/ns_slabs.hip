@@ -824,6 +824,16 @@ extern "C" int nsk_slabs_set_option(nsk_slabs *g, const char *name, int value) {
   return 2;
 }
 
+extern "C" int nsk_slabs_get_option(nsk_slabs *g, const char *name, int *value) {
+  NSK_GROUP(g, 0);
+  NSK_REQUIRE(name != nullptr && value != nullptr, "nsk_slabs_get_option: null argument");
+  if (!strcmp(name, "edges_first")) *value = g->edges_first;
+  else if (!strcmp(name, "deadline_ms")) *value = g->deadline_ms;
+  else if (!strcmp(name, "first_contact_ms")) *value = g->first_contact_ms;
+  else return nsk_get_option(g->slabs[0].ctx, name, value);  // what the first local slab's kernels use
+  return 0;
+}
+
 extern "C" int nsk_slabs_info(nsk_slabs *g, int *world, int *nlocal, int *transport, int *exchanges) {
   NSK_GROUP(g, 0);
   if (world) *world = g->world;

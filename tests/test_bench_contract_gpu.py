@@ -33,11 +33,18 @@ def test_single_gpu_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
     assert r["algorithmic_bytes_per_launch"] == 40.0 * 2559 * 4095 * r["passes_per_launch"]
+    # the kernel's time comes from the timed loop itself: it cannot exceed the loop's wall time
+    assert r["launches_per_step"] == 240 / r["passes_per_launch"]
+    assert r["launch_us"] * r["launches_per_step"] <= j["ms_per_step"] * 1e3 * (1 + 1e-9)
+    assert r["launch_us"] * r["launches_per_step"] > 0.8 * j["ms_per_step"] * 1e3      # and is most of it
+    assert "fabric" in r["traffic_kind"] and "hbm_frac" not in r
     if r["traffic"] is not None:        # counters taken from this very kernel build
-        assert 0.2 < r["hbm_frac"] < 1.0 and 0.2 < r["valu_frac"] < 1.0
+        assert 0.2 < r["fabric_frac"] < 1.0 and 0.2 < r["valu_frac"] < 1.0
+        assert r["valu_frac_sustained"] is None or r["valu_frac"] * 0.9 < r["valu_frac_sustained"] < 1.0
+        assert abs(r["frac_of_bound"] - max(r["fabric_frac"], r["valu_frac"], r["valu_frac_sustained"] or 0.0)) < 1e-12
         assert r["traffic"] >= 0.15 * r["algorithmic_bytes_per_launch"]
     else:
-        assert r["hbm_frac"] is None and r["valu_frac"] is None
+        assert r["fabric_frac"] is None and r["valu_frac"] is None and r["frac_of_bound"] is None
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "GB/s" and 1 <= c["cores"] <= c["cores_present"] and c["value"] > 0
     assert "passes" in c["sample"]
@@ -69,6 +76,35 @@ def test_two_rank_line_as_the_driver_launches_it():
     assert j["exchanges_timed"] == 2 * 3 and j["comm_exposed_us_per_exchange"] > 0      # ceil(150 / 60) per step
     assert abs(j["value"] - 40.0 * 2559 * 4095 * 2 / (j["t_iter_us"] * 1e-6) / 1e9) < 1e-6 * j["value"]
     assert "cpu_baseline" not in j and "time_steps" not in j
+    # who took part, gathered from every rank
+    assert j["world_size"] == 2 and j["backend"] == "gloo" and [e["rank"] for e in j["ranks"]] == [0, 1]
+    assert all(e["device"] == "cuda:0" and e["name"] for e in j["ranks"]) and j["distinct_devices"] == 1
+    assert len({e["pid"] for e in j["ranks"]}) == 2
+    r = j["roofline"]
+    assert r["launch_us"] * r["launches_per_step"] <= j["ms_per_step"] * 1e3 * (1 + 1e-9)
+
+
+def test_first_contact_has_a_deadline():
+    """A rank that never arrives (here: rank 1 sleeps instead of joining the process group) must not hang
+    the run: the other rank's watchdog says where it was and the command ends with a non-zero status
+    within the deadline."""
+    import socket
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "0", "--passes", "60", "--backend", "gloo", "--one-gpu",
+           "--first-contact-s", "6"]
+    t0 = time.time()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT,
+                         env=dict(os.environ, NSK_BENCH_TEST_STALL="1"))
+    assert out.returncode != 0 and time.time() - t0 < 60
+    assert "no completion within 6 s -- rank 0 of 2 on cuda:0" in out.stderr, out.stderr[-3000:]
+    assert "phase: process group set-up" in out.stderr and "peers [1]" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]        # no result line
 
 
 def test_traffic_record_matches_the_build():
