@@ -54,22 +54,22 @@ namespace {
 constexpr int NSK_MAX_DEVICES = 64;
 double *g_static_ptr[NSK_MAX_DEVICES];  // address of `scratch` on each device, null = not looked up
 struct StaticLayout {                   // what the last call on a device left in the partners
-  int ld, ldd, ny, embedded;
+  int nx, ld, ldd, ny, embedded;
 } g_static_layout[NSK_MAX_DEVICES];
+std::mutex g_static_mu;                 // guards the two tables (contexts of several threads share a device's array)
 }  // namespace
 
 // Called by nsk_create with `device` current: the address of this device's copy of `scratch`.
 int nsk_i_static_scratch_init(int device, double **out) {
   NSK_REQUIRE(device >= 0 && device < NSK_MAX_DEVICES, "device %d beyond the %d the static scratch table holds", device,
               NSK_MAX_DEVICES);
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
+  std::lock_guard<std::mutex> lock(g_static_mu);
   if (!g_static_ptr[device]) {
     double *ptr = nullptr;
     NSK_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
     NSK_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned a null address for the static scratch");
     g_static_ptr[device] = ptr;
-    g_static_layout[device] = StaticLayout{0, 0, 0, 0};
+    g_static_layout[device] = StaticLayout{0, 0, 0, 0, 0};
   }
   *out = g_static_ptr[device];
   return 0;
@@ -494,11 +494,18 @@ extern "C" int nsk_ns_poisson_iters_static(nsk_ctx *ctx, double *Pr, double *dPr
   // writes every value the next launch uses, but pad columns and unused rim cells are read as
   // don't-care lanes: with a new layout they would hold whatever the last layout left there, so
   // the part in use is cleared when the layout changes.
-  StaticLayout &last = g_static_layout[ctx->device];
-  if (last.ld != ld || last.ldd != ldd || last.ny != p->ny || last.embedded != p->dp_embedded) {
+  // (nx is part of the layout: grids of different width can share a pitch, and the columns between the
+  // narrower grid's last one and the pitch would otherwise keep the wider grid's values)
+  bool clear;
+  {
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    StaticLayout &last = g_static_layout[ctx->device];
+    clear = last.nx != p->nx || last.ld != ld || last.ldd != ldd || last.ny != p->ny || last.embedded != p->dp_embedded;
+    last = StaticLayout{p->nx, ld, ldd, p->ny, p->dp_embedded};
+  }
+  if (clear) {
     NSK_HIP(hipMemsetAsync(part_pr, 0, elems * sizeof(double), ctx->stream));
     NSK_HIP(hipMemsetAsync(part_dp, 0, elems * sizeof(double), ctx->stream));
-    last = StaticLayout{ld, ldd, p->ny, p->dp_embedded};
   }
   return iters_with_partners(ctx, Pr, dPrdtau, divV, p, count, part_pr, part_dp);
 }

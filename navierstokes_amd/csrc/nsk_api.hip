@@ -1,6 +1,8 @@
 // Context, error, stream and memory entry points of libnsk.
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "nsk_internal.h"
 
@@ -55,6 +57,22 @@ extern "C" int nsk_create(int device, nsk_ctx **out) {
   }
   *out = c;
   return 0;
+}
+
+hipError_t nsk_allow_lds(nsk_ctx *ctx, const void *kernel, size_t bytes) {
+  struct Key {
+    const void *kernel;
+    int device;
+    bool operator<(const Key &o) const { return kernel != o.kernel ? kernel < o.kernel : device < o.device; }
+  };
+  static std::mutex mu;
+  static std::map<Key, size_t> allowed;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t &have = allowed[Key{kernel, ctx->device}];
+  if (have >= bytes) return hipSuccess;
+  const hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (rc == hipSuccess) have = bytes;
+  return rc;
 }
 
 extern "C" int nsk_destroy(nsk_ctx *c) {

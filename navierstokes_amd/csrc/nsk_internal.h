@@ -53,12 +53,6 @@ struct nsk_ctx {
   size_t sor_snap_elems = 0;
   unsigned long long *run_words = nullptr;  // per-step counters of nsk_bub_dns_run / nsk_bub_code3_run
   size_t run_words_cap = 0;
-  // Largest dynamic LDS size already allowed for a kernel through this context (the attribute call
-  // costs microseconds, a time step of the bubble drivers a hundred).
-  struct LdsAllowed {
-    const void *kernel;
-    size_t bytes;
-  } lds_allowed[16] = {};
   int step_fused = 1;    // nsk_ns_step: 1 = three fused kernels around the Poisson loop, 0 = one launch per call site
   int poisson_rows = 0;  // rows per task chunk, 0 = automatic (NSK_POISSON_ROWS / nsk_set_option)
   int code3_steps_done = 0;  // complete time steps of the last nsk_bub_code3_step / _run call
@@ -78,25 +72,10 @@ int nsk_sor_grid(nsk_ctx *ctx, int mode, double *a, const double *c1, const doub
 
 void nsk_set_error(const char *fmt, ...);
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) unless this context has already allowed the
-// kernel at least `bytes`.
-inline hipError_t nsk_allow_lds(nsk_ctx *ctx, const void *kernel, size_t bytes) {
-  nsk_ctx::LdsAllowed *slot = nullptr;
-  for (auto &e : ctx->lds_allowed) {
-    if (e.kernel == kernel) {
-      if (e.bytes >= bytes) return hipSuccess;
-      slot = &e;
-      break;
-    }
-    if (!e.kernel && !slot) slot = &e;
-  }
-  const hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (rc == hipSuccess && slot) {
-    slot->kernel = kernel;
-    slot->bytes = bytes;
-  }
-  return rc;
-}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) unless the kernel has already been allowed at least
+// `bytes` on this context's device.  The attribute belongs to (kernel, device), not to a context: the
+// table is shared by all contexts and only ever raises a kernel's limit.
+hipError_t nsk_allow_lds(nsk_ctx *ctx, const void *kernel, size_t bytes);
 
 #define NSK_HIP(call)                                                          \
   do {                                                                         \

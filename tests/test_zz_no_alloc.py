@@ -55,6 +55,65 @@ def test_static_entry_point_equals_allocating_one(gpu, oracle):
             assert same_bits(got_Pr, Pr) and same_bits(got_dP, dP), (nx, ny, pitched, count)
 
 
+def test_static_entry_point_same_pitch_narrower_grid(gpu):
+    """Two grids of different width can share a row pitch (140 and 130 columns both take 144): the columns
+    between the narrower grid's last one and the pitch then hold what the wider grid left there -- huge and
+    non-finite values here -- unless the call clears them, as the allocating entry point's partners are."""
+    rng = np.random.default_rng(22)
+    wide = ns_params("NavierStokes", nx=140, ny=67)
+    assert _pitch(140) == _pitch(130) == 144
+    Pw = rng_field(rng, 140, 67) * 1e300
+    Pw[131:, :] = np.inf
+    Pw[135, 5] = np.nan
+    run(gpu, "ns_poisson_iters_static", wide, Pw, rng_field(rng, 138, 65) * 1e300, rng_field(rng, 140, 67), 7, True)
+    p = ns_params("NavierStokes", nx=130, ny=67)
+    Pr0, dP0, dv = rng_field(rng, 130, 67), rng_field(rng, 128, 65), rng_field(rng, 130, 67, 10.0)
+    for count in (9, 4):
+        want = run(gpu, "ns_poisson_iters", p, Pr0, dP0, dv, count, True)
+        got = run(gpu, "ns_poisson_iters_static", p, Pr0, dP0, dv, count, True)
+        assert same_bits(got[0], want[0]) and same_bits(got[1], want[1]), count
+
+
+def test_static_entry_point_allocates_nothing():
+    """What the entry point is for: on a context whose ping-pong partners and staging copies do not exist
+    yet, calls of the static entry point leave the device's free memory where it was -- in both storage
+    forms, the dense one included, which the allocating entry point would stage through copies of its own
+    on a long run."""
+    import torch
+    torch.cuda.synchronize()
+    ctx = _lib.Context(0, torch.cuda.current_stream().cuda_stream)        # fresh: nothing allocated on demand yet
+    try:
+        rng = np.random.default_rng(23)
+        nx, ny = 301, 199
+        p = ns_params("NavierStokes", nx=nx, ny=ny)
+        Pr0, dP0, dv = rng_field(rng, nx, ny), rng_field(rng, nx - 2, ny - 2), rng_field(rng, nx, ny, 10.0)
+        ld = _pitch(nx)
+        emb = np.zeros((nx, ny), order="F")
+        emb[1:-1, 1:-1] = dP0
+        arrays = {True: (Dev(Pr0, ld), Dev(emb, ld), Dev(dv, ld), c_params(p, ld_pr=ld, dp_embedded=1)),
+                  False: (Dev(Pr0), Dev(dP0), Dev(dv), c_params(p))}
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(0)[0]
+        for pitched in (True, False):
+            a, b, c, cp = arrays[pitched]
+            for count in (64, 5):                   # 64 passes: a run the allocating entry point would stage when dense
+                ctx.ns_poisson_iters_static(a.ptr, b.ptr, c.ptr, C.byref(cp), count)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] == free0
+        # ... while the allocating entry point, on the same context, does take memory for its partners
+        a, b, c, cp = arrays[True]
+        big = ns_params("NavierStokes", nx=1279, ny=2047)
+        t = torch.zeros((3, 2047, _pitch(1279)), dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        free1 = torch.cuda.mem_get_info(0)[0]
+        cpb = c_params(big, ld_pr=_pitch(1279), dp_embedded=1)
+        ctx.ns_poisson_iters(C.c_void_p(t[0].data_ptr()), C.c_void_p(t[1].data_ptr()), C.c_void_p(t[2].data_ptr()), C.byref(cpb), 4)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] < free1
+    finally:
+        ctx.close()
+
+
 def test_static_entry_point_from_a_second_context(gpu):
     """The array belongs to the GPU, not to a context: a second context uses the same one."""
     import torch
