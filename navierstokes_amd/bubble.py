@@ -73,6 +73,34 @@ class DNSParams:
     pressure_solver: str = "sor"
     damp: float = 0.72
     cfl_tau: float = 0.9 / 2 ** 0.5
+    # cell-centre coordinates that set_density! tests against: "code1" = dx*(i-1.5) (code1.m:22),
+    # "linrange" = LinRange(-0.5dx, Lx+0.5dx, nx+2) as DNS.jl:46-47 builds them (the two differ in the
+    # last bit of some coordinates, which can move a cell across the drop's edge)
+    grid: str = "code1"
+
+    @classmethod
+    def dns_jl(cls, **kw) -> "DNSParams":
+        """scripts/DNS.jl:16-47 as written: maxit 400, LinRange coordinates."""
+        return cls(**{"grid": "linrange", "maxit": 400, **kw})
+
+    @classmethod
+    def dns_loop_jl(cls, **kw) -> "DNSParams":
+        """scripts/DNS_loop.jl:20-58: maxit 200 and the time step from its two CFL numbers,
+        dt = min(CFL_visc*dy^2*rho1/m0, CFL_adv*dy/1.0) (:43-52), LinRange coordinates."""
+        q = cls(**{"grid": "linrange", "maxit": 200, **kw})
+        if "dt" not in kw:
+            cfl_visc, cfl_adv = 1 / 4.1, 1.0
+            q.dt = min(cfl_visc * (q.dy * q.dy) * q.rho1 / q.m0, cfl_adv * q.dy / 1.0)
+        return q
+
+    def centres(self):
+        """xc, yc of DNS.jl:46-47 / code1.m:22 (see `grid`)."""
+        if self.grid == "linrange":
+            return (linrange(-0.5 * self.dx, self.Lx + 0.5 * self.dx, self.nx + 2),
+                    linrange(-0.5 * self.dy, self.Ly + 0.5 * self.dy, self.ny + 2))
+        if self.grid != "code1":
+            raise ValueError(f"unknown grid {self.grid!r}")
+        return cell_centres(self.nx, self.dx), cell_centres(self.ny, self.dy)
 
     @property
     def dtau(self):
@@ -93,6 +121,11 @@ def _ctx(device):
     dev = torch.device(device)
     torch.cuda.set_device(dev)
     return dev, _lib.Context(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
+
+
+def linrange(a: float, b: float, n: int) -> np.ndarray:
+    """Julia's LinRange(a, b, n) element by element: (1-t)*a + t*b with t = (i-1)/(n-1)."""
+    return np.array([(1 - i / (n - 1)) * a + (i / (n - 1)) * b for i in range(n)]) if n > 1 else np.array([a])
 
 
 def cell_centres(n: int, d: float) -> np.ndarray:
@@ -116,8 +149,9 @@ class DNS:
         self.tmp1, self.tmp2 = A(nx + 2, ny + 2), A(nx + 2, ny + 2)
         self.dPdtau = A(nx + 2, ny + 2)  # code1_perf_gpu.jl:183 (used by pressure_solver="pt")
         self.xc, self.yc = A(nx + 2), A(ny + 2)
-        self.xc.set(cell_centres(nx, q.dx))
-        self.yc.set(cell_centres(ny, q.dy))
+        xc, yc = q.centres()
+        self.xc.set(xc)
+        self.yc.set(yc)
         # DNS.jl:64-67
         self.ctx.bub_set_density(self.rho.ptr, None, q.xcenter, q.ycenter, self.xc.ptr, self.yc.ptr,
                                  q.rad, q.rho2, 0.0, nx, ny)

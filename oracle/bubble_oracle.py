@@ -70,8 +70,8 @@ class OracleDNS:
         self.ut, self.vt = F(nx + 1, ny + 2), F(nx + 2, ny + 1)
         self.uu, self.vv = F(nx + 1, ny + 1), F(nx + 1, ny + 1)
         self.tmp1, self.tmp2 = F(nx + 2, ny + 2), F(nx + 2, ny + 2)
-        self.o.set_density(self.rho, None, q.xcenter, q.ycenter, cell_centres(nx, q.dx), cell_centres(ny, q.dy),
-                           q.rad, q.rho2, 0.0, nx, ny)
+        xc, yc = q.centres() if hasattr(q, "centres") else (cell_centres(nx, q.dx), cell_centres(ny, q.dy))
+        self.o.set_density(self.rho, None, q.xcenter, q.ycenter, xc, yc, q.rad, q.rho2, 0.0, nx, ny)
 
     def _step_with(self, solver) -> int:
         """The body of bub_code1_step from its parts, with another pressure solver."""

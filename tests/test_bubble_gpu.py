@@ -363,6 +363,25 @@ def test_dns_steps_other_solvers(solver):
         assert same_bits(getattr(g, k).get(), getattr(o, k)), k
 
 
+@pytest.mark.parametrize("preset", ["dns_jl", "dns_loop_jl"])
+def test_dns_presets_of_the_two_scripts(preset):
+    """scripts/DNS.jl as written (maxit 400, cell centres from LinRange(-0.5dx, Lx+0.5dx, nx+2), DNS.jl:46-47) and
+    scripts/DNS_loop.jl (maxit 200, dt from its two CFL numbers, DNS_loop.jl:43-52): 12 steps against the oracle
+    run with the same parameter block."""
+    q = getattr(DNSParams, preset)()
+    assert q.grid == "linrange" and q.maxit == (400 if preset == "dns_jl" else 200)
+    if preset == "dns_loop_jl":
+        assert q.dt == min((1 / 4.1) * (q.dy * q.dy) * q.rho1 / q.m0, 1.0 * q.dy / 1.0) and q.dt != 0.00125
+    g, o = DNS(q), OracleDNS(q)
+    xc, _ = q.centres()
+    assert xc[0] == -0.5 * q.dx and xc[-1] == q.Lx + 0.5 * q.dx and same_bits(g.xc.get(), xc)
+    assert same_bits(g.rho.get(), o.rho)
+    for _ in range(12):
+        assert g.step() == o.step()
+    for k in ("rho", "u", "v", "p", "uu", "vv"):
+        assert same_bits(getattr(g, k).get(), getattr(o, k)), k
+
+
 @pytest.mark.parametrize("form", STEP_FORMS)
 @pytest.mark.parametrize("nx,ny,Nf", [(32, 32, 100), (21, 40, 57)])
 def test_code3_steps(form, nx, ny, Nf):
