@@ -52,7 +52,9 @@ const char *nsk_version(void);
                                   * scripts/code3_fun.jl:462-465 resizes its vectors; see
                                   * nsk_bub_code3_run_status for how a caller continues */
 #define NSK_ERR_TIMEOUT 5        /* nsk_slabs_*: a host-side wait behind an exchange or an all-reduce ran into
-                                  * its deadline (nsk_slabs_set_option "deadline_ms", "first_contact_ms") */
+                                  * its deadline (nsk_slabs_set_option "deadline_ms", "first_contact_ms");
+                                  * nsk_sync / nsk_download / residuals: a kernel whose workgroups wait for each
+                                  * other gave up (nsk_set_option "poisson_small") */
 #define NSK_ERR_FRONT_OUTSIDE 4  /* a front point left the box [0,Lx] x [0,Ly]: the reference prints a
                                   * message (scripts/code3_fun.jl:186-188) and its next array access
                                   * by that point throws; the state is not to be used */
@@ -76,6 +78,22 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *                          division; a form the two divisors dx, dy do not qualify for is replaced
  *                          by the next exact one (2 -> 3 -> 4 -> IEEE)
  *   "poisson_div_used"     (read only) the form the last fused Poisson call ran
+ *   "poisson_small"        nsk_ns_poisson_iters on whole domains whose tiles fit on chip (up to 256 tiles of up
+ *                          to 4096 cells with their frames; 153 x 255 uses 209), runs of 12 passes or
+ *                          more: 1 = the whole run in one launch, the fields in LDS and registers, tiles
+ *                          handing their outer cells to their neighbours every "poisson_small_halo"
+ *                          passes (default), 0 = launches of "poisson_k" passes.  "poisson_k" and
+ *                          "poisson_rows_used" read back the run's length and the tile height then.  A
+ *                          wait between workgroups that runs out of polls ends the launch; the next
+ *                          nsk_sync / nsk_download / residual of the context returns NSK_ERR_TIMEOUT.
+ *   "poisson_small_halo"   passes between two hand-overs = width of a tile's frame (0 = 8)
+ *   "poisson_small_cols", "poisson_small_rows"  tile of a workgroup (0 = the smallest square tiles that
+ *                          cover the grid with no more workgroups than compute units)
+ *   "poisson_small_spin_limit"  polls before a workgroup gives up on a neighbour (0 = 2^22)
+ *   "poisson_small_test_absent" testing: 1 + the workgroup that leaves at once (0 = none)
+ *   "poisson_tall_percent" launches of "poisson_k" passes: interior tasks in pairs of
+ *                          poisson_rows * (100 +- this) / 100 rows that start together, so that the last
+ *                          round of tasks ends evenly (0 = all alike, the default: at most 2 % gained)
  *   "poisson_edge_task_rows" nsk_ns_poisson_iters_edges_first: rows per task of the edge rows' launch
  *                          (0 = 6)
  *   "sor_pipeline"         nsk_bub_solve_pressure / nsk_bub_construct_den: 1 = several lexicographic sweeps

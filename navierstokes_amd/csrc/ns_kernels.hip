@@ -266,6 +266,7 @@ int nsk_read_maxabs(nsk_ctx *ctx, double *out) {
   NSK_HIP(hipMemcpyAsync(ctx->red_host, ctx->red_dev, sizeof(unsigned long long),
                          hipMemcpyDeviceToHost, ctx->stream));
   NSK_HIP(hipStreamSynchronize(ctx->stream));
+  if (int rc = nsk_device_error_check(ctx, "residual")) return rc;
   unsigned long long b = *ctx->red_host;
   double d;
   memcpy(&d, &b, sizeof d);

@@ -294,24 +294,10 @@ struct EdgesFirst {
 // long before the interior's (whose height the planner picks for throughput).
 constexpr int EDGE_TASK_ROWS = 6;
 
-// `count` passes in place, with part_pr / part_dp as the ping-pong partners (same layout as the
-// caller's arrays).  Allocates nothing.  With `ef`, the last launch is cut in three: the edge rows
-// (both edges in one launch of short tasks, on ef->stream), the interior (on the context's stream)
-// and the skipped rows, which are not produced.  The interior is planned for fewer wavefront slots
-// than the chip has, so that the edge tasks find theirs although the interior is dispatched a few
-// microseconds ahead of them (unplanned, the interior's tasks took every slot and the edge rows
-// were ready no earlier than the interior -- measured).  What the caller queues on ef->stream
-// afterwards (the transfer) follows the edge tasks in that stream's order, on a hardware queue the
-// interior is not on; three streams (edge, interior, transfer) were too many: HIP maps streams
-// onto four hardware queues and two of the three shared one -- measured.
-int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double *divV, const nsk_ns_params *p,
-                        int count, double *part_pr, double *part_dp, const EdgesFirst *ef = nullptr) {
+// The parts of the kernel arguments that depend on the parameters only; returns the division form.
+int constants_of(nsk_ctx *ctx, const nsk_ns_params *p, const double *divV, PoissonArgs *out) {
   const int nx = p->nx, ny = p->ny, ld = ld_pr_of(p), ldd = ld_dp_of(p);
-  const bool aligned = vector_storage(Pr, dPrdtau, divV, p);
-  const size_t pr_elems = (size_t)ld * ny;
-  const size_t dp_elems = p->dp_embedded ? pr_elems : (size_t)ldd * (ny - 2);
-
-  PoissonArgs A;
+  PoissonArgs &A = *out;
   memset(&A, 0, sizeof A);
   A.divv = divV;
   A.nx = nx;
@@ -340,6 +326,28 @@ int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double 
   const unsigned forms = reciprocal_for(p->dx, &A.rdx_h, &A.rdx_l) & reciprocal_for(p->dy, &A.rdy_h, &A.rdy_l);
   const int div = pick_division_form(forms, ctx->poisson_div);
   ctx->last_div = div;
+  return div;
+}
+
+// `count` passes in place, with part_pr / part_dp as the ping-pong partners (same layout as the
+// caller's arrays).  Allocates nothing.  With `ef`, the last launch is cut in three: the edge rows
+// (both edges in one launch of short tasks, on ef->stream), the interior (on the context's stream)
+// and the skipped rows, which are not produced.  The interior is planned for fewer wavefront slots
+// than the chip has, so that the edge tasks find theirs although the interior is dispatched a few
+// microseconds ahead of them (unplanned, the interior's tasks took every slot and the edge rows
+// were ready no earlier than the interior -- measured).  What the caller queues on ef->stream
+// afterwards (the transfer) follows the edge tasks in that stream's order, on a hardware queue the
+// interior is not on; three streams (edge, interior, transfer) were too many: HIP maps streams
+// onto four hardware queues and two of the three shared one -- measured.
+int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double *divV, const nsk_ns_params *p,
+                        int count, double *part_pr, double *part_dp, const EdgesFirst *ef = nullptr) {
+  const int nx = p->nx, ny = p->ny, ld = ld_pr_of(p), ldd = ld_dp_of(p);
+  const bool aligned = vector_storage(Pr, dPrdtau, divV, p);
+  const size_t pr_elems = (size_t)ld * ny;
+  const size_t dp_elems = p->dp_embedded ? pr_elems : (size_t)ldd * (ny - 2);
+
+  PoissonArgs A;
+  const int div = constants_of(ctx, p, divV, &A);
 
   // Passes per launch and task shape: forced by the options, otherwise the cheapest by the
   // planner's estimate for this grid.
@@ -419,11 +427,22 @@ extern "C" int nsk_ns_poisson_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, c
   if (int rc = check_params(p)) return rc;
   NSK_REQUIRE(count >= 0, "negative pass count %d", count);
   if (count == 0) return 0;
-  if (!vector_storage(Pr, dPrdtau, divV, p) && ctx->poisson_stage && count >= STAGE_MIN_PASSES)
-    return staged_iters(ctx, Pr, dPrdtau, divV, p, count);
   // ping-pong partners use the layout of the caller's arrays
   const size_t pr_elems = (size_t)ld_pr_of(p) * p->ny;
   const size_t dp_elems = p->dp_embedded ? pr_elems : (size_t)ld_dp_of(p) * (p->ny - 2);
+  SmallPlan tiles;
+  if (small_grid_applies(ctx, p, count, &tiles)) {  // fields that fit on chip: one launch
+    if (int rc = ensure_pingpong(ctx, pr_elems > dp_elems ? pr_elems : dp_elems)) return rc;
+    PoissonArgs A;
+    const int div = constants_of(ctx, p, divV, &A);
+    ctx->last_plan_k = count;
+    ctx->last_plan_rows = tiles.tile_rows;
+    ctx->last_div = div == DIV_FMA2 ? DIV_FMA2 : DIV_IEEE;
+    return small_grid_iters(ctx, Pr, dPrdtau, divV, p, count, A, div == DIV_FMA2 ? DIV_FMA2 : DIV_IEEE, ctx->pp_pr,
+                            ctx->pp_dp, tiles);
+  }
+  if (!vector_storage(Pr, dPrdtau, divV, p) && ctx->poisson_stage && count >= STAGE_MIN_PASSES)
+    return staged_iters(ctx, Pr, dPrdtau, divV, p, count);
   if (int rc = ensure_pingpong(ctx, pr_elems > dp_elems ? pr_elems : dp_elems)) return rc;
   return iters_with_partners(ctx, Pr, dPrdtau, divV, p, count, ctx->pp_pr, ctx->pp_dp);
 }

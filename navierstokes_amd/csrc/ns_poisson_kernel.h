@@ -34,6 +34,10 @@ struct PoissonArgs {
   int nstrips, nchunks, rows_per_chunk;   // interior strips: chunks and rows per chunk
   int nchunks_edge, rows_per_chunk_edge;  // the first and the last strip do more work per row
   int n_interior_tasks;
+  // Unequal task heights (0 = all chunks alike): the chunks of the interior strips come in pairs of a tall
+  // one (rows_per_chunk + tall_extra rows) and, above it, a short one (rows_per_chunk - tall_extra); the
+  // tall chunks take the first half of the workgroup numbers, see k_poisson.
+  int tall_extra, pair_tasks, pair_tasks_pad;
   int xcd_bands;  // nonzero: XCD-aware task numbering
   int xbc_rows;            // rows r < xbc_rows (0-based) receive the x-Neumann condition
   int phys_bottom, phys_top;
@@ -648,7 +652,36 @@ __global__ void __launch_bounds__(64) NSK_WAVES_ATTR k_poisson(PoissonArgs A) {
   // Tasks: first the interior strips (1 .. nstrips-2) x their chunks, then the two edge strips
   // (0 and nstrips-1) with their own, shorter chunks.
   int task = blockIdx.x, sx, r0, r1;
-  if (task < A.n_interior_tasks) {
+  if (A.tall_extra > 0 && task < A.n_interior_tasks) {
+    // The two wavefronts that share a SIMD do not share it evenly: the one that arrived first is served
+    // first and runs at nearly the speed it would have alone, the other fills the gaps and then finishes
+    // alone.  Workgroups are handed out in the order of their numbers, so the first half of the numbers
+    // are the first arrivals: they get the tall chunk of a pair, the second half the short one, and the
+    // two finish together.  XCD-aware as below: workgroup i runs on XCD i % 8, and XCD x works on a
+    // contiguous band of pairs (both chunks of each).
+    const int nb = A.pair_tasks_pad >> 3;  // pairs per band
+    int pt, tall;
+    if (A.xcd_bands) {
+      const int x = task & 7, k = task >> 3;
+      tall = k < nb;
+      pt = x * nb + (tall ? k : k - nb);
+    } else {
+      tall = task < A.pair_tasks_pad;
+      pt = tall ? task : task - A.pair_tasks_pad;
+    }
+    if (pt >= A.pair_tasks) return;  // padding of the pair count to a multiple of 8
+    const int nint = A.nstrips - 2;
+    sx = 1 + pt % nint;
+    const int base = A.row_begin + (pt / nint) * 2 * A.rows_per_chunk;
+    if (tall) {
+      r0 = base;
+      r1 = min(r0 + A.rows_per_chunk + A.tall_extra, A.row_end);
+    } else {
+      r0 = base + A.rows_per_chunk + A.tall_extra;
+      r1 = min(base + 2 * A.rows_per_chunk, A.row_end);
+    }
+    if (r0 >= r1) return;
+  } else if (task < A.n_interior_tasks) {
     if (A.xcd_bands) {
       // Workgroup i runs on XCD i % 8, each with its own L2.  Give every XCD a contiguous band
       // of chunks over all strips, so that tasks that read the same halo columns (and rows)
@@ -702,6 +735,16 @@ __global__ void __launch_bounds__(64) NSK_WAVES_ATTR k_poisson(PoissonArgs A) {
 }
 
 // ---- host side: how a launch is cut into tasks -------------------------------------------------
+
+// Whole runs of passes in one launch on grids whose fields fit on chip (ns_poisson_small.hip): tiles of
+// tile_cols x tile_rows cells, gx x gy of them, a frame of `halo` cells around each, `slots` cells per thread.
+struct SmallPlan {
+  int tile_cols, tile_rows, halo, gx, gy, slots;
+};
+struct PoissonArgs;
+bool small_grid_applies(const nsk_ctx *ctx, const nsk_ns_params *p, int count, SmallPlan *plan);
+int small_grid_iters(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double *divV, const nsk_ns_params *p, int count,
+                     const PoissonArgs &P, int div, double *part_pr, double *part_dp, const SmallPlan &plan);
 
 // Geometry of one launch: strips of WOUT output columns x chunks of rows.  The first and the last
 // strip carry the boundary-column work on top, so their chunks are shorter.
@@ -824,7 +867,20 @@ int launch_k(nsk_ctx *ctx, hipStream_t stream, PoissonArgs &A, bool aligned, int
   A.nchunks1_edge = plan.nchunks1_edge >= 0 ? plan.nchunks1_edge : plan.nchunks_edge;
   A.n_interior_tasks = (plan.nstrips > 2 ? plan.nstrips - 2 : 0) * plan.nchunks;
   A.xcd_bands = ctx->poisson_xcd;
-  const unsigned tasks = (unsigned)plan.tasks;
+  unsigned tasks = (unsigned)plan.tasks;
+  A.tall_extra = A.pair_tasks = A.pair_tasks_pad = 0;
+  // pairs of a tall and a short chunk: whole-window launches of two wavefronts per SIMD only (with one
+  // wavefront per SIMD nobody shares, and the two-range launches of the edges-first schedule are short anyway)
+  const int extra = plan.rows * ctx->poisson_tall_percent / 100;
+  if (extra > 0 && extra < plan.rows && plan.nchunks1 < 0 && plan.nstrips > 2 && plan.tasks > ctx->num_simds) {
+    const int nint = plan.nstrips - 2, nrows = A.row_end - A.row_begin;
+    const int npairs = (nrows + 2 * plan.rows - 1) / (2 * plan.rows);
+    A.tall_extra = extra;
+    A.pair_tasks = nint * npairs;
+    A.pair_tasks_pad = (A.pair_tasks + 7) / 8 * 8;
+    tasks = tasks - (unsigned)A.n_interior_tasks + 2u * (unsigned)A.pair_tasks_pad;
+    A.n_interior_tasks = 2 * A.pair_tasks_pad;
+  }
 #define NSK_LAUNCH(AL, DV) k_poisson<K, AL, DV><<<tasks, 64, 0, stream>>>(A)
   // the hint is built for the form every shipped grid takes; the other forms do without
   const bool hint = ctx->poisson_stream < 0 ? stream_inputs(A.nx, A.ny) : ctx->poisson_stream != 0;

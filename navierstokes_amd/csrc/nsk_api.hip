@@ -45,6 +45,7 @@ extern "C" int nsk_create(int device, nsk_ctx **out) {
     nsk_destroy(c);
     return 1;
   }
+  memset(c->red_host, 0, 256);
   // (a failure here only disables nsk_ns_poisson_iters_static, which then reports it)
   if (nsk_i_static_scratch_init(device, &c->static_scratch) != 0) c->static_scratch = nullptr;
   if (const char *k = getenv("NSK_POISSON_K")) {
@@ -91,6 +92,7 @@ extern "C" int nsk_destroy(nsk_ctx *c) {
   if (c->sor_snap) (void)hipFree(c->sor_snap);
   if (c->sor_grid_ctl) (void)hipFree(c->sor_grid_ctl);
   if (c->run_words) (void)hipFree(c->run_words);
+  if (c->small_xbuf) (void)hipFree(c->small_xbuf);
   if (c->ev_edge) (void)hipEventDestroy(c->ev_edge);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->hist_dev) (void)hipFree(c->hist_dev);
@@ -176,6 +178,31 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
     ctx->poisson_edge_percent = value;
     return 0;
   }
+  if (!strcmp(name, "poisson_small")) {
+    NSK_REQUIRE(value == 0 || value == 1, "poisson_small must be 0 or 1, got %d", value);
+    ctx->poisson_small = value;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_small_spin_limit") || !strcmp(name, "poisson_small_test_absent")) {
+    NSK_REQUIRE(value >= 0, "%s must be >= 0, got %d", name, value);
+    (name[14] == 's' ? ctx->poisson_small_spin_limit : ctx->poisson_small_test_absent) = value;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_small_halo")) {
+    NSK_REQUIRE(value >= 0 && value <= 64, "poisson_small_halo must be 0..64, got %d", value);
+    ctx->poisson_small_halo = value;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_small_rows") || !strcmp(name, "poisson_small_cols")) {
+    NSK_REQUIRE(value >= 0, "%s must be >= 0, got %d", name, value);
+    (name[14] == 'r' ? ctx->poisson_small_rows : ctx->poisson_small_cols) = value;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_tall_percent")) {
+    NSK_REQUIRE(value >= -1 && value <= 95, "poisson_tall_percent must be -1..95, got %d", value);
+    ctx->poisson_tall_percent = value;
+    return 0;
+  }
   if (!strcmp(name, "poisson_div")) {
     NSK_REQUIRE(value == -1 || value == 0 || value == 2 || value == 3 || value == 4,
                 "poisson_div must be -1 (automatic), 0, 2, 3 or 4, got %d", value);
@@ -249,6 +276,22 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
     *value = ctx->poisson_edge_percent;
     return 0;
   }
+  if (!strcmp(name, "poisson_small")) {
+    *value = ctx->poisson_small;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_small_halo")) {
+    *value = ctx->poisson_small_halo;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_small_rows") || !strcmp(name, "poisson_small_cols")) {
+    *value = name[14] == 'r' ? ctx->poisson_small_rows : ctx->poisson_small_cols;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_tall_percent")) {
+    *value = ctx->poisson_tall_percent;
+    return 0;
+  }
   if (!strcmp(name, "poisson_div")) {
     *value = ctx->poisson_div;
     return 0;
@@ -261,10 +304,20 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   return 2;
 }
 
+int nsk_device_error_check(nsk_ctx *ctx, const char *where) {
+  volatile unsigned long long *word = ctx->red_host + NSK_DEVICE_ERROR_WORD;
+  if (*word == 0) return 0;
+  *word = 0;
+  nsk_set_error("%s: a kernel of this context gave up waiting for another workgroup of its launch (a bounded wait "
+                "between workgroups ran out); the arrays that launch was writing hold undefined values",
+                where);
+  return NSK_ERR_TIMEOUT;
+}
+
 extern "C" int nsk_sync(nsk_ctx *ctx) {
   NSK_CTX(ctx);
   NSK_HIP(hipStreamSynchronize(ctx->stream));
-  return 0;
+  return nsk_device_error_check(ctx, "nsk_sync");
 }
 
 extern "C" int nsk_zeros(nsk_ctx *ctx, int n1, int n2, double **out) {
@@ -299,7 +352,7 @@ extern "C" int nsk_download(nsk_ctx *ctx, double *host, const double *dev, size_
   NSK_NONNULL(host, dev);
   NSK_HIP(hipMemcpyAsync(host, dev, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   NSK_HIP(hipStreamSynchronize(ctx->stream));
-  return 0;
+  return nsk_device_error_check(ctx, "nsk_download");
 }
 
 extern "C" int nsk_copy(nsk_ctx *ctx, double *dst, const double *src, size_t count) {

@@ -41,6 +41,7 @@ struct nsk_ctx {
   int poisson_div = -1;  // -1 = automatic; 0 / 2 / 3 / 4 ask for a division form (testing)
   int last_div = -1;     // form the last fused Poisson call used (nsk_get_option "poisson_div_used")
   int poisson_edge_percent = 0;  // rows per task of the edge strips in % of poisson_rows, 0 = default
+  int poisson_tall_percent = 0;  // interior chunks in pairs of poisson_rows*(100 +- this)/100 rows, 0 = all alike
   int poisson_xcd = 1;   // XCD-aware task numbering of the Poisson kernel (0 = plain)
   int poisson_stream = -1;  // non-temporal requests for Pr and dPrdtau rows: -1 = by the size of the fields, 0 / 1
   int edge_task_rows = 0;  // task height of the edge rows in nsk_ns_poisson_iters_edges_first, 0 = default
@@ -63,7 +64,21 @@ struct nsk_ctx {
   unsigned *sor_grid_ctl = nullptr;
   size_t sor_grid_words = 0, sor_grid_zero = 0;
   int sor_grid_ti = 0, sor_grid_tj = 0;
+  // Poisson passes of small grids in one launch (ns_poisson_small.hip): exchange rows + progress words
+  int poisson_small = 1;       // 1 = grids whose fields fit on chip run a whole call in one launch, 0 = never
+  int poisson_small_halo = 0;  // passes between two exchanges of edge rows, 0 = default
+  int poisson_small_rows = 0, poisson_small_cols = 0;  // tile of a workgroup, 0 = by the grid
+  int poisson_small_spin_limit = 0;   // polls before a workgroup gives up on a neighbour, 0 = default
+  int poisson_small_test_absent = 0;  // testing: 1 + the workgroup that leaves at once
+  double *small_xbuf = nullptr;
+  size_t small_xbuf_elems = 0, small_words = 0;
+  int small_trace_at = 0, small_trace_groups = 0;  // debug builds (-DNSK_SMALL_TRACE)
 };
+
+// Word of red_host that a kernel sets when one of its bounded waits ran out.
+constexpr int NSK_DEVICE_ERROR_WORD = 24;
+// After a synchronisation of the context's stream: has a kernel given up on a wait since the last look?
+int nsk_device_error_check(nsk_ctx *ctx, const char *where);
 
 // bubble_sor_grid.hip
 int nsk_sor_grid(nsk_ctx *ctx, int mode, double *a, const double *c1, const double *c2, const double *c3,

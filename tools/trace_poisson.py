@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--k", type=int, default=5)
 ap.add_argument("--rows", type=int, default=0)
 ap.add_argument("--edge", type=int, default=0)
+ap.add_argument("--tall", type=int, default=0, help="poisson_tall_percent")
 a = ap.parse_args()
 p = ns_params("NavierStokes_Re6", n=16)
 nx, ny = p.nx, p.ny
@@ -35,6 +36,7 @@ ptr = lambda t: C.c_void_p(t.data_ptr())
 ctx.set_option("poisson_k", a.k)
 ctx.set_option("poisson_rows", a.rows)
 ctx.set_option("poisson_edge_percent", a.edge)
+ctx.set_option("poisson_tall_percent", a.tall)
 ctx.ns_poisson_iters(ptr(Pr), ptr(dP), ptr(dv), C.byref(cp), a.k * 6)
 torch.cuda.synchronize()
 lib = _lib.load()
@@ -74,3 +76,24 @@ for x in range(8):
         print(f"xcc {x}: tasks {m.sum()} finish max {en[m].max():.1f} mean dur {dur[m].mean():.1f}")
 nt = len(b)
 print("edge tasks mean dur", dur[idx >= idx.max() - 200].mean() if nt > 300 else None)
+
+# workgroups are handed out in the order of their numbers: how do the first and the second half fare?
+half = (idx.max() + 1) // 2
+for name, m in (("first half of the workgroup numbers", idx < half), ("second half", idx >= half)):
+    if m.any():
+        print(f"{name}: {m.sum()} tasks, start mean {st[m].mean():.1f}, duration mean {dur[m].mean():.1f} p10 {np.percentile(dur[m],10):.1f} "
+              f"p90 {np.percentile(dur[m],90):.1f}, end mean {en[m].mean():.1f} max {en[m].max():.1f}")
+# pairs on one SIMD: the one with the smaller workgroup number against the other
+order_by_simd = {}
+for i_, k_ in enumerate(key):
+    order_by_simd.setdefault(int(k_), []).append(i_)
+first, second = [], []
+for v_ in order_by_simd.values():
+    if len(v_) == 2:
+        a_, b_ = sorted(v_, key=lambda i_: idx[i_])
+        first.append(a_); second.append(b_)
+if first:
+    first, second = np.array(first), np.array(second)
+    print(f"SIMDs with two tasks: {len(first)}; smaller number: duration mean {dur[first].mean():.1f}, end mean {en[first].mean():.1f}; "
+          f"larger number: duration mean {dur[second].mean():.1f}, end mean {en[second].mean():.1f}; "
+          f"pairs whose smaller number is in the first half and larger in the second: {int(((idx[first] < half) & (idx[second] >= half)).sum())}")
