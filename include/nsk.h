@@ -358,7 +358,10 @@ int nsk_slabs_sync(nsk_slabs *g);
  * `rows` owned rows of Pr to itself and receives them into the first `rows` owned rows of divV. */
 int nsk_slabs_rccl_self_exchange(nsk_slabs *g, int rows);
 int nsk_slabs_info(nsk_slabs *g, int *world, int *nlocal, int *transport, int *exchanges);
-/* Switches with no effect on any result: "edges_first" (default 1) -- the last launch of every
+/* Switches with no effect on any result: "step_fused" (default 1) -- nsk_slabs_step runs the three fused
+ * kernels of nsk_ns_step around the Poisson loop, on windows (guards on window rows, cylinder mask and
+ * boundary conditions on global rows), 0 = one launch per kernel of NavierStokes.jl:79-100.
+ * "edges_first" (default 1) -- the last launch of every
  * block of Poisson passes produces the rows the neighbours wait for first
  * (nsk_ns_poisson_iters_edges_first), so that the halo exchange runs beside the rest of that
  * launch; 0 = whole window, then the exchange.

@@ -27,6 +27,11 @@
 
 #include "nsk_internal.h"
 
+// ns_step_fused.hip
+int nsk_i_step_predictor(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_params *p);
+int nsk_i_step_corrector(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_params *p);
+int nsk_i_step_advect_out(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_params *p);
+
 namespace {
 
 // ---- RCCL entry points, resolved on first use ---------------------------------------------------
@@ -148,6 +153,7 @@ struct nsk_slabs {
   int first_contact_ms = 180000, deadline_ms = 60000;
   bool contact_made = false;
   int test_stall_ms = 0;  // (testing) the next exchange is held back on the device for this long
+  bool step_fused = true;  // nsk_slabs_step: three fused kernels around the Poisson loop instead of eleven launches
   size_t last_exchange_bytes = 0;
 };
 
@@ -754,11 +760,11 @@ extern "C" int nsk_slabs_step(nsk_slabs *g, int *iters_out, double *err_hist, in
     if (int rc_ = (call)) return rc_
   // rows the back-trace of advect! may reach, |Vy| dt/dy + 1 below / above (one halo row is stale by then:
   // predict_V! / correct_V! do not update a window's outermost row)
-  auto reach_of_advect = [&](double *reach) -> int {
+  auto reach_of_advect = [&](double *reach, bool corrected_in_o = false) -> int {
     unsigned long long m = 0;
     for (Slab &s : g->slabs) {
       double v = 0.0;
-      if (int rc = nsk_maxabs(s.ctx, s.Vy, (size_t)nx * (s.ny_win + 1), &v)) return rc;
+      if (int rc = nsk_maxabs(s.ctx, corrected_in_o ? s.Vy_o : s.Vy, (size_t)nx * (s.ny_win + 1), &v)) return rc;
       unsigned long long b;
       memcpy(&b, &v, sizeof b);
       m = b > m ? b : m;
@@ -777,31 +783,65 @@ extern "C" int nsk_slabs_step(nsk_slabs *g, int *iters_out, double *err_hist, in
     NSK_REQUIRE(reach <= g->halo - 1, "advect! would reach %.1f rows but only %d valid halo rows exist: raise the halo width "
                 "(nothing was changed)", reach, g->halo - 1);
   }
-  // :79-82
-  NSK_EACH(nsk_update_tau(s.ctx, s.txx, s.tyy, s.txy, s.Vx, s.Vy, p->mu, p->dx, p->dy, nx, s.ny_win));
-  NSK_EACH(nsk_predict_V(s.ctx, s.Vx, s.Vy, s.txx, s.tyy, s.txy, p->rho, p->g, p->dt, p->dx, p->dy, nx, s.ny_win));
-  NSK_EACH(nsk_set_sphere(s.ctx, s.C, s.Vx, s.Vy, p->a2, p->b2, p->ox, p->oy, p->sinb, p->cosb, p->lx, p->ly, p->dx,
-                          p->dy, nx, s.ny_win, s.iy0));
-  NSK_EACH(nsk_update_divV_ld(s.ctx, s.divV, g->ld, s.Vx, s.Vy, p->dx, p->dy, nx, s.ny_win));
-  if (int rc = exchange_fields(g, 4)) return rc;
-  // :84-95
-  if (int rc = nsk_slabs_poisson(g, iters_out, err_hist, iter_hist, hist_cap, nhist_out)) return rc;
-  // :96-98
-  NSK_EACH(nsk_correct_V_ld(s.ctx, s.Vx, s.Vy, s.Pr, g->ld, p->dt, p->rho, p->dx, p->dy, nx, s.ny_win));
-  NSK_EACH(nsk_set_sphere(s.ctx, s.C, s.Vx, s.Vy, p->a2, p->b2, p->ox, p->oy, p->sinb, p->cosb, p->lx, p->ly, p->dx,
-                          p->dy, nx, s.ny_win, s.iy0));
-  NSK_EACH(nsk_set_bc_Vel(s.ctx, s.Vx, s.Vy, s.Vprof, nx, s.ny_win, p->full_rows, s.iy0, nyg));
-  if (g->world > 1) {
-    double reach = 0.0;
-    if (int rc = reach_of_advect(&reach)) return rc;
-    NSK_REQUIRE(reach <= g->halo - 1, "advect! reaches %.1f rows but only %d valid halo rows exist: the windows hold a "
-                "half-finished time step; set the group up again with a wider halo", reach, g->halo - 1);
+  if (g->step_fused) {
+    // Three kernels around the Poisson loop (ns_step_fused.hip), on windows: the predictor leaves the new
+    // fields in the *_o arrays, the corrector works there in place, advect! brings them back.
+    auto state_of = [](const Slab &s) {
+      nsk_ns_state st{};
+      st.Pr = s.Pr, st.dPrdtau = s.dP, st.divV = s.divV, st.Vprof = s.Vprof;
+      st.Vx = s.Vx, st.Vy = s.Vy, st.C = s.C, st.Vx_o = s.Vx_o, st.Vy_o = s.Vy_o, st.C_o = s.C_o;
+      return st;
+    };
+    for (Slab &s : g->slabs) {
+      NSK_HIP(hipSetDevice(s.device));
+      const nsk_ns_state st = state_of(s);
+      if (int rc = nsk_i_step_predictor(s.ctx, &st, &s.prm)) return rc;  // :79-82
+    }
+    if (int rc = exchange_fields(g, 4)) return rc;
+    if (int rc = nsk_slabs_poisson(g, iters_out, err_hist, iter_hist, hist_cap, nhist_out)) return rc;  // :84-95
+    for (Slab &s : g->slabs) {
+      NSK_HIP(hipSetDevice(s.device));
+      const nsk_ns_state st = state_of(s);
+      if (int rc = nsk_i_step_corrector(s.ctx, &st, &s.prm)) return rc;  // :96-98
+    }
+    if (g->world > 1) {
+      double reach = 0.0;
+      if (int rc = reach_of_advect(&reach, true)) return rc;
+      NSK_REQUIRE(reach <= g->halo - 1, "advect! reaches %.1f rows but only %d valid halo rows exist: the windows hold a "
+                  "half-finished time step; set the group up again with a wider halo", reach, g->halo - 1);
+    }
+    for (Slab &s : g->slabs) {
+      NSK_HIP(hipSetDevice(s.device));
+      const nsk_ns_state st = state_of(s);
+      if (int rc = nsk_i_step_advect_out(s.ctx, &st, &s.prm)) return rc;  // :99-100
+    }
+  } else {
+    // :79-82
+    NSK_EACH(nsk_update_tau(s.ctx, s.txx, s.tyy, s.txy, s.Vx, s.Vy, p->mu, p->dx, p->dy, nx, s.ny_win));
+    NSK_EACH(nsk_predict_V(s.ctx, s.Vx, s.Vy, s.txx, s.tyy, s.txy, p->rho, p->g, p->dt, p->dx, p->dy, nx, s.ny_win));
+    NSK_EACH(nsk_set_sphere(s.ctx, s.C, s.Vx, s.Vy, p->a2, p->b2, p->ox, p->oy, p->sinb, p->cosb, p->lx, p->ly, p->dx,
+                            p->dy, nx, s.ny_win, s.iy0));
+    NSK_EACH(nsk_update_divV_ld(s.ctx, s.divV, g->ld, s.Vx, s.Vy, p->dx, p->dy, nx, s.ny_win));
+    if (int rc = exchange_fields(g, 4)) return rc;
+    // :84-95
+    if (int rc = nsk_slabs_poisson(g, iters_out, err_hist, iter_hist, hist_cap, nhist_out)) return rc;
+    // :96-98
+    NSK_EACH(nsk_correct_V_ld(s.ctx, s.Vx, s.Vy, s.Pr, g->ld, p->dt, p->rho, p->dx, p->dy, nx, s.ny_win));
+    NSK_EACH(nsk_set_sphere(s.ctx, s.C, s.Vx, s.Vy, p->a2, p->b2, p->ox, p->oy, p->sinb, p->cosb, p->lx, p->ly, p->dx,
+                            p->dy, nx, s.ny_win, s.iy0));
+    NSK_EACH(nsk_set_bc_Vel(s.ctx, s.Vx, s.Vy, s.Vprof, nx, s.ny_win, p->full_rows, s.iy0, nyg));
+    if (g->world > 1) {
+      double reach = 0.0;
+      if (int rc = reach_of_advect(&reach)) return rc;
+      NSK_REQUIRE(reach <= g->halo - 1, "advect! reaches %.1f rows but only %d valid halo rows exist: the windows hold a "
+                  "half-finished time step; set the group up again with a wider halo", reach, g->halo - 1);
+    }
+    // :99-100
+    NSK_EACH(nsk_copy(s.ctx, s.Vx_o, s.Vx, (size_t)(nx + 1) * s.ny_win));
+    NSK_EACH(nsk_copy(s.ctx, s.Vy_o, s.Vy, (size_t)nx * (s.ny_win + 1)));
+    NSK_EACH(nsk_copy(s.ctx, s.C_o, s.C, (size_t)nx * s.ny_win));
+    NSK_EACH(nsk_advect(s.ctx, s.Vx, s.Vx_o, s.Vy, s.Vy_o, s.C, s.C_o, p->dt, p->dx, p->dy, nx, s.ny_win, s.iy0, nyg));
   }
-  // :99-100
-  NSK_EACH(nsk_copy(s.ctx, s.Vx_o, s.Vx, (size_t)(nx + 1) * s.ny_win));
-  NSK_EACH(nsk_copy(s.ctx, s.Vy_o, s.Vy, (size_t)nx * (s.ny_win + 1)));
-  NSK_EACH(nsk_copy(s.ctx, s.C_o, s.C, (size_t)nx * s.ny_win));
-  NSK_EACH(nsk_advect(s.ctx, s.Vx, s.Vx_o, s.Vy, s.Vy_o, s.C, s.C_o, p->dt, p->dx, p->dy, nx, s.ny_win, s.iy0, nyg));
 #undef NSK_EACH
   const XField xf[3] = {xfield(g, F_VX), xfield(g, F_C), xfield(g, F_VY)};
   if (int rc = exchange_list(g, xf, 3, g->halo)) return rc;
@@ -813,6 +853,10 @@ extern "C" int nsk_slabs_set_option(nsk_slabs *g, const char *name, int value) {
   NSK_REQUIRE(name != nullptr, "nsk_slabs_set_option: name is null");
   if (!strcmp(name, "edges_first")) {
     g->edges_first = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "step_fused")) {
+    g->step_fused = value != 0;
     return 0;
   }
   if (!strcmp(name, "deadline_ms") || !strcmp(name, "first_contact_ms") || !strcmp(name, "test_stall_ms")) {
@@ -828,6 +872,7 @@ extern "C" int nsk_slabs_get_option(nsk_slabs *g, const char *name, int *value) 
   NSK_GROUP(g, 0);
   NSK_REQUIRE(name != nullptr && value != nullptr, "nsk_slabs_get_option: null argument");
   if (!strcmp(name, "edges_first")) *value = g->edges_first;
+  else if (!strcmp(name, "step_fused")) *value = g->step_fused;
   else if (!strcmp(name, "deadline_ms")) *value = g->deadline_ms;
   else if (!strcmp(name, "first_contact_ms")) *value = g->first_contact_ms;
   else return nsk_get_option(g->slabs[0].ctx, name, value);  // what the first local slab's kernels use

@@ -1,5 +1,7 @@
 // The time-step body outside the Poisson loop as three kernels instead of eleven launches
-// (scripts/NavierStokes.jl:79-82 and :96-100 on a whole domain):
+// (scripts/NavierStokes.jl:79-82 and :96-100), on a whole domain or on a window of rows of one (a slab
+// with halo rows: guards on the window's rows, the cylinder mask and the boundary conditions on global
+// rows, exactly as the single kernels treat windows):
 //
 //   k_predictor   update_τ! + predict_V! + set_sphere! + update_∇V!   (:116-132, :225-250)
 //                 out of place: reads Vx, Vy, C, writes the predicted and masked fields into the
@@ -20,8 +22,10 @@
 namespace {
 
 struct StepArgs {
-  int nx, ny, ld;                 // ld: leading dimension of Pr and ∇V
-  int xrows;                      // rows of Vy that bc_x! reaches (NavierStokes.jl:155,181)
+  int nx, ny, ld;                 // ny: rows of the window; ld: leading dimension of Pr and ∇V
+  int iy0, nyg;                   // the window holds global rows iy0+1 .. iy0+ny of nyg
+  int bottom, top;                // the window's first / last row is the domain's
+  int xrows;                      // window rows of Vy that bc_x! reaches (NavierStokes.jl:155,181)
   double mu, dtr, rg, dx, dy;     // dtr = dt/ρ, rg = ρ*g
   double a2, b2, ox, oy, sinb, cosb, lx, ly, dt;
 };
@@ -31,7 +35,7 @@ struct Mask {
   bool c, vx, vy;
 };
 __device__ __forceinline__ Mask mask_at(const StepArgs &a, int ix, int iy) {
-  const double xv = (double)(ix - 1) * a.dx - a.lx / 2, yv = (double)(iy - 1) * a.dy - a.ly / 2;
+  const double xv = (double)(ix - 1) * a.dx - a.lx / 2, yv = (double)(iy + a.iy0 - 1) * a.dy - a.ly / 2;
   const double xc = xv + a.dx / 2, yc = yv + a.dx / 2;  // (dx in yc as in the reference, :227)
   Mask m;
   {
@@ -151,16 +155,17 @@ __global__ void __launch_bounds__(256) k_corrector(double *__restrict__ Vx, doub
     if (i >= 2 && i <= nx && j >= 2 && j <= ny - 1)
       v = v - a.dtr * (A2(Pr, a.ld, i, j) - A2(Pr, a.ld, i - 1, j)) / a.dx;  // correct_V! :150
     if (m.vx) v = 0.0;
-    if (j != 1 && j != ny) A2(Vx, nx + 1, i, j) = v;  // rows 1 and ny are copies of rows 2 and ny-1 (bc_y!)
-    if (j == 2) A2(Vx, nx + 1, i, 1) = v;
-    if (j == ny - 1) A2(Vx, nx + 1, i, ny) = v;
+    // the domain's rows 1 and ny are copies of rows 2 and ny-1 (bc_y!); a window's other end rows are its own
+    if (!(j == 1 && a.bottom) && !(j == ny && a.top)) A2(Vx, nx + 1, i, j) = v;
+    if (j == 2 && a.bottom) A2(Vx, nx + 1, i, 1) = v;
+    if (j == ny - 1 && a.top) A2(Vx, nx + 1, i, ny) = v;
   }
   if (i <= nx) {  // Vy (nx, ny+1)
-    if (j == 1) {
+    if (j == 1 && a.bottom) {
       A2(Vy, nx, i, 1) = Vprof[i - 1];  // bc_yV!: the bottom row is the inflow profile
-    } else if (j <= ny) {
+    } else if (!(j == ny + 1 && a.top)) {
       double v = A2(Vy, nx, i, j);
-      if (i >= 2 && i <= nx - 1)
+      if (i >= 2 && i <= nx - 1 && j >= 2 && j <= ny)
         v = v - a.dtr * (A2(Pr, a.ld, i, j) - A2(Pr, a.ld, i, j - 1)) / a.dy;  // correct_V! :151
       if (m.vy) v = 0.0;
       const bool xbc = j <= a.xrows;  // bc_x! reaches this row
@@ -168,14 +173,14 @@ __global__ void __launch_bounds__(256) k_corrector(double *__restrict__ Vx, doub
       if (own) A2(Vy, nx, i, j) = v;
       if (xbc && i == 2) A2(Vy, nx, 1, j) = v;
       if (xbc && i == nx - 1) A2(Vy, nx, nx, j) = v;
-      if (j == ny) {  // bc_yV!: the top row takes row ny as bc_x! left it
+      if (j == ny && a.top) {  // bc_yV!: the top row takes row ny as bc_x! left it
         if (own) A2(Vy, nx, i, ny + 1) = v;
         if (xbc && i == 2) A2(Vy, nx, 1, ny + 1) = v;
         if (xbc && i == nx - 1) A2(Vy, nx, nx, ny + 1) = v;
       }
     }
-    // (row ny+1 itself: written by the thread of row ny; bc_x! on row ny+1, when it reaches that far,
-    //  acts before bc_yV! overwrites the whole row, so it leaves no trace)
+    // (the domain's row ny+1 itself: written by the thread of row ny; bc_x! on row ny+1, when it reaches that
+    //  far, acts before bc_yV! overwrites the whole row, so it leaves no trace)
   }
 }
 
@@ -186,12 +191,18 @@ __device__ __forceinline__ int clamp_floor(double f, int lo, int hi) {
   if (f >= (double)hi) return hi;
   return (int)f;
 }
-// backtrack!  NavierStokes.jl:192-202
-__device__ __forceinline__ double backtrack(const double *__restrict__ A_o, int n1, int n2, double vxc, double vyc,
-                                            double dt, double dx, double dy, int ix, int iy) {
+// backtrack!  NavierStokes.jl:192-202.  (ix, gy) are global indices; the source window holds global rows
+// iy0+1 .. iy0+n2w of an array with n2g rows (the extra clamp to the window only acts when the window's
+// halo is too narrow for the back-trace, which the caller excludes).
+__device__ __forceinline__ double backtrack(const double *__restrict__ A_o, int n1, int n2w, int n2g, int iy0, double vxc,
+                                            double vyc, double dt, double dx, double dy, int ix, int gy) {
   double ddx = dt * vxc / dx, ddy = dt * vyc / dy;
-  const int ix1 = clamp_floor(floor((double)ix - ddx), 1, n1), iy1 = clamp_floor(floor((double)iy - ddy), 1, n2);
-  const int ix2 = min(ix1 + 1, n1), iy2 = min(iy1 + 1, n2);
+  const int ix1 = clamp_floor(floor((double)ix - ddx), 1, n1);
+  int iy1 = clamp_floor(floor((double)gy - ddy), 1, n2g);
+  const int ix2 = min(ix1 + 1, n1);
+  int iy2 = min(iy1 + 1, n2g);
+  iy1 = min(max(iy1 - iy0, 1), n2w);
+  iy2 = min(max(iy2 - iy0, 1), n2w);
   ddx = (double)(ddx > 0) - fmod(ddx, 1.0);
   ddy = (double)(ddy > 0) - fmod(ddy, 1.0);
   const double fx1 = lerp_ref(A2(A_o, n1, ix1, iy1), A2(A_o, n1, ix2, iy1), ddx);
@@ -200,7 +211,8 @@ __device__ __forceinline__ double backtrack(const double *__restrict__ A_o, int 
 }
 
 // advect!  NavierStokes.jl:206-223; points it leaves alone (first and last column of Vx, first and
-// last row of Vy) keep the value they have in the source arrays.
+// last row of Vy -- of the window: a window's end rows are halo rows or the domain's) keep the value they
+// have in the source arrays.
 __global__ void __launch_bounds__(256) k_advect_out(double *__restrict__ Vx, const double *__restrict__ Vx_o,
                                                     double *__restrict__ Vy, const double *__restrict__ Vy_o,
                                                     double *__restrict__ C, const double *__restrict__ C_o,
@@ -208,12 +220,13 @@ __global__ void __launch_bounds__(256) k_advect_out(double *__restrict__ Vx, con
   const int nx = a.nx, ny = a.ny;
   const int ix = blockIdx.x * 64 + (threadIdx.x & 63) + 1, iy = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
   if (ix > nx + 1 || iy > ny + 1) return;
+  const int gy = iy + a.iy0;
   if (iy <= ny) {
     double v = A2(Vx_o, nx + 1, ix, iy);
     if (ix > 1 && ix < nx + 1) {
       const double vyc = 0.25 * (A2(Vy_o, nx, ix - 1, iy) + A2(Vy_o, nx, ix - 1, iy + 1) + A2(Vy_o, nx, ix, iy) +
                                  A2(Vy_o, nx, ix, iy + 1));
-      v = backtrack(Vx_o, nx + 1, ny, v, vyc, a.dt, a.dx, a.dy, ix, iy);
+      v = backtrack(Vx_o, nx + 1, ny, a.nyg, a.iy0, v, vyc, a.dt, a.dx, a.dy, ix, gy);
     }
     A2(Vx, nx + 1, ix, iy) = v;
   }
@@ -222,14 +235,14 @@ __global__ void __launch_bounds__(256) k_advect_out(double *__restrict__ Vx, con
     if (iy > 1 && iy < ny + 1) {
       const double vxc = 0.25 * (A2(Vx_o, nx + 1, ix, iy - 1) + A2(Vx_o, nx + 1, ix + 1, iy - 1) +
                                  A2(Vx_o, nx + 1, ix, iy) + A2(Vx_o, nx + 1, ix + 1, iy));
-      v = backtrack(Vy_o, nx, ny + 1, vxc, v, a.dt, a.dx, a.dy, ix, iy);
+      v = backtrack(Vy_o, nx, ny + 1, a.nyg + 1, a.iy0, vxc, v, a.dt, a.dx, a.dy, ix, gy);
     }
     A2(Vy, nx, ix, iy) = v;
   }
   if (ix <= nx && iy <= ny) {
     const double vxc = 0.5 * (A2(Vx_o, nx + 1, ix, iy) + A2(Vx_o, nx + 1, ix + 1, iy));
     const double vyc = 0.5 * (A2(Vy_o, nx, ix, iy) + A2(Vy_o, nx, ix, iy + 1));
-    A2(C, nx, ix, iy) = backtrack(C_o, nx, ny, vxc, vyc, a.dt, a.dx, a.dy, ix, iy);
+    A2(C, nx, ix, iy) = backtrack(C_o, nx, ny, a.nyg, a.iy0, vxc, vyc, a.dt, a.dx, a.dy, ix, gy);
   }
 }
 
@@ -238,8 +251,13 @@ StepArgs step_args(const nsk_ns_params *p) {
   a.nx = p->nx;
   a.ny = p->ny;
   a.ld = p->ld_pr ? p->ld_pr : p->nx;
-  const int rows_vy = p->ny + 1;
-  a.xrows = p->full_rows ? rows_vy : (p->nx < rows_vy ? p->nx : rows_vy);
+  a.iy0 = p->iy0;
+  a.nyg = p->nyg;
+  a.bottom = p->iy0 == 0;
+  a.top = p->iy0 + p->ny == p->nyg;
+  const int rows_vy = p->nyg + 1;
+  const int xrows_global = p->full_rows ? rows_vy : (p->nx < rows_vy ? p->nx : rows_vy);
+  a.xrows = xrows_global - p->iy0 < 0 ? 0 : (xrows_global - p->iy0 > p->ny + 1 ? p->ny + 1 : xrows_global - p->iy0);
   a.mu = p->mu;
   a.dtr = p->dt / p->rho;
   a.rg = p->rho * p->g;
@@ -268,13 +286,25 @@ int nsk_i_step_predictor(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_param
   return 0;
 }
 
-// NavierStokes.jl:96-98 in place on (Vx_o, Vy_o, C_o), then :100 back into (Vx, Vy, C).
-int nsk_i_step_corrector_advect(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_params *p) {
+// NavierStokes.jl:96-98 in place on (Vx_o, Vy_o, C_o).
+int nsk_i_step_corrector(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_params *p) {
   const StepArgs a = step_args(p);
   dim3 grid(nsk_cdiv(p->nx + 1, 64), nsk_cdiv(p->ny + 1, 4));
   k_corrector<<<grid, 256, 0, ctx->stream>>>(s->Vx_o, s->Vy_o, s->C_o, s->Pr, s->Vprof, a);
   NSK_LAUNCH_CHECK();
+  return 0;
+}
+
+// NavierStokes.jl:100 from (Vx_o, Vy_o, C_o) back into (Vx, Vy, C); :99 has nothing left to do.
+int nsk_i_step_advect_out(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_params *p) {
+  const StepArgs a = step_args(p);
+  dim3 grid(nsk_cdiv(p->nx + 1, 64), nsk_cdiv(p->ny + 1, 4));
   k_advect_out<<<grid, 256, 0, ctx->stream>>>(s->Vx, s->Vx_o, s->Vy, s->Vy_o, s->C, s->C_o, a);
   NSK_LAUNCH_CHECK();
   return 0;
+}
+
+int nsk_i_step_corrector_advect(nsk_ctx *ctx, const nsk_ns_state *s, const nsk_ns_params *p) {
+  if (int rc = nsk_i_step_corrector(ctx, s, p)) return rc;
+  return nsk_i_step_advect_out(ctx, s, p);
 }

@@ -154,11 +154,13 @@ def test_slabs_of_the_benchmark_width(gpu, oracle):
         g.close()
 
 
-@pytest.mark.parametrize("world,halo,nx,ny_loc,transport", [(2, 8, 45, 40, 2), (3, 12, 54, 30, 2), (1, 0, 45, 60, 1)])
-def test_whole_time_steps_on_slabs(gpu, world, halo, nx, ny_loc, transport):
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("world,halo,nx,ny_loc,transport", [(2, 8, 45, 40, 2), (3, 12, 54, 30, 2), (1, 0, 45, 60, 1), (4, 6, 45, 20, 2)])
+def test_whole_time_steps_on_slabs(gpu, world, halo, nx, ny_loc, transport, fused):
     """nsk_slabs_step = NavierStokes.jl:79-100 on slabs (windows of every array, exchanges of divV, Pr,
     dPrdtau, Vx, C and the face field Vy, the reach check of advect!): three steps from the reference's
-    initial condition against the single-domain oracle; with one slab the RCCL group does the same."""
+    initial condition against the single-domain oracle; with one slab the RCCL group does the same.  Around
+    the Poisson loop either the three fused kernels on windows (the default) or one launch per kernel."""
     from navierstokes_amd.ns import init_vprof
     from oracle.ns_oracle import OracleSim
     nyg = world * ny_loc
@@ -167,6 +169,8 @@ def test_whole_time_steps_on_slabs(gpu, world, halo, nx, ny_loc, transport):
                    unique_id=_lib.rccl_unique_id() if transport == 1 else None)
     ref = OracleSim(p)
     try:
+        g.set_option("step_fused", fused)
+        assert g.get_option("step_fused") == fused
         g.init_flow(init_vprof(p))
         for _ in range(3):
             it = ref.step()
