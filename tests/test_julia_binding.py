@@ -2,7 +2,10 @@
 checked statically: every `ccall((:name, lib), Ret, (types...), args...)` is parsed and compared
 with the prototype of `name` in include/nsk.h (return type, number and C type of each argument,
 number of values passed), the two structs are compared field by field with the header, and every
-function the header declares must have a stub."""
+function the header declares must have a stub.  Types alone would let two same-typed scalars change
+places (dx and dy, say), so the NAMES are compared too: a value whose name -- Greek letters spelled
+out, field accessors dropped -- is the name of a parameter of the C function must be passed in that
+parameter's place."""
 import os
 import re
 
@@ -26,6 +29,29 @@ def header_prototypes():
             types.append(" ".join(a.replace("*", " * ").split()))
         protos[name] = (ret, types)
     return protos
+
+
+def header_parameter_names():
+    text = strip_comments(open(os.path.join(ROOT, "include", "nsk.h")).read())
+    text = re.sub(r"typedef struct \w+ \{.*?\} \w+;", "", text, flags=re.S)
+    names = {}
+    for m in re.finditer(r"(?:const char \*|int )\s*(nsk_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = " ".join(m.group(2).split())
+        params = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        names[m.group(1)] = [re.search(r"(\w+)$", a).group(1) if re.search(r"\w$", a) else "" for a in params]
+    return names
+
+
+GREEK = {"τ": "tau", "μ": "mu", "ρ": "rho", "β": "b", "∇V": "divV", "∇": "div", "Δ": "d", "σ": "sigma", "ε": "eps", "α": "alpha"}
+
+
+def spelled_out(value):
+    """`τxx.p` -> `tauxx`, `dτ` -> `dtau`, `sinβ` -> `sinb`; anything that is not a plain name -> ''."""
+    v = value.strip()
+    v = re.sub(r"\.p$", "", v)
+    for g, latin in GREEK.items():
+        v = v.replace(g, latin)
+    return v if re.fullmatch(r"[A-Za-z_]\w*", v) else ""
 
 
 C_TO_JULIA = {
@@ -102,6 +128,31 @@ def test_every_ccall_matches_its_prototype():
         assert len(args) == len(types), f"{f}: {name}: {len(types)} types but {len(args)} values"
         for i, (jt, ct) in enumerate(zip(types, ctypes_)):
             assert jt in C_TO_JULIA[ct], f"{f}: {name} argument {i + 1} is `{ct}` in the header, `{jt}` in the ccall"
+
+
+def test_named_values_are_passed_in_their_parameters_place():
+    names = header_parameter_names()
+    checked, functions = 0, set()
+    for f, name, _, _, args in julia_ccalls():
+        params = names[name]
+        for i, a in enumerate(args):
+            v = spelled_out(a)
+            if v and params.count(v) == 1:
+                assert params.index(v) == i, (f"{f}: {name}: `{a.strip()}` is passed as argument {i + 1} ({params[i]}), "
+                                              f"but the header's `{v}` is argument {params.index(v) + 1}")
+                checked += 1
+                functions.add(name)
+    # most scalar arguments carry the header's names (dx, dy, dt, rho, mu, ...): the check has teeth
+    assert checked >= 250 and len(functions) >= 40, (checked, len(functions))
+
+
+def test_the_name_check_sees_a_swap():
+    names = {"nsk_x": ["ctx", "A", "dx", "dy", "nx"]}
+    args = ["c.h", "A.p", "dy", "dx", "A.n1"]
+    params = names["nsk_x"]
+    wrong = [a for i, a in enumerate(args) if spelled_out(a) in params and params.index(spelled_out(a)) != i]
+    assert wrong == ["dy", "dx"]
+    assert spelled_out("τxx.p") == "tauxx" and spelled_out("dτ") == "dtau" and spelled_out("Pr.n1") == "" and spelled_out("∇V.p") == "divV"
 
 
 def test_every_declared_function_has_a_stub():

@@ -267,15 +267,19 @@ def test_planner_picks_passes_per_launch_by_grid(gpu, oracle):
     (every choice is covered by the parity tests above); here only the choice is checked."""
     for opt in ("poisson_k", "poisson_rows"):
         gpu.set_option(opt, 0)
-    rng = np.random.default_rng(77)
-    for n, want in ((1, (1, 2, 3, 4)), (16, (5, 6))):
-        p = ns_params("NavierStokes_Re6", n=n)
-        Pr0, dP0, dv = rng_field(rng, p.nx, p.ny, 1e-2), rng_field(rng, p.nx - 2, p.ny - 2, 1e-2), rng_field(rng, p.nx, p.ny, 1e-2)
-        run_gpu(gpu, p, Pr0, dP0, dv, 40, 0, True)
-        assert gpu.get_option("poisson_k") in want, (n, gpu.get_option("poisson_k"))
-        assert gpu.get_option("poisson_rows_used") >= 2
-    run_gpu(gpu, p, Pr0, dP0, dv, 3, 0, True)
-    assert gpu.get_option("poisson_k") <= 3
+    gpu.set_option("poisson_small", 0)      # (the small grid would otherwise run its 40 passes in one launch)
+    try:
+        rng = np.random.default_rng(77)
+        for n, want in ((1, (1, 2, 3, 4)), (16, (5, 6))):
+            p = ns_params("NavierStokes_Re6", n=n)
+            Pr0, dP0, dv = rng_field(rng, p.nx, p.ny, 1e-2), rng_field(rng, p.nx - 2, p.ny - 2, 1e-2), rng_field(rng, p.nx, p.ny, 1e-2)
+            run_gpu(gpu, p, Pr0, dP0, dv, 40, 0, True)
+            assert gpu.get_option("poisson_k") in want, (n, gpu.get_option("poisson_k"))
+            assert gpu.get_option("poisson_rows_used") >= 2
+        run_gpu(gpu, p, Pr0, dP0, dv, 3, 0, True)
+        assert gpu.get_option("poisson_k") <= 3
+    finally:
+        gpu.set_option("poisson_small", 1)
 
 
 @pytest.mark.parametrize("nx,ny", [(45, 75), (130, 67), (257, 300)])

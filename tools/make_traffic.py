@@ -31,6 +31,15 @@ for path in a.dbs:
             "select counter_name, avg(value), count(*) from counters_collection "
             "where kernel_name like ? group by counter_name", (f"%k_poisson<{a.k},%",)):
         vals[name] = (avg, n)
+# the kernel's duration in the pass that counted SQ_BUSY_CYCLES: cycles / duration = the clock it ran at
+launch_us = None
+for path in a.dbs:
+    cur = sqlite3.connect(path).cursor()
+    has = cur.execute("select count(*) from counters_collection where counter_name = 'SQ_BUSY_CYCLES'").fetchone()[0]
+    if has:
+        row = cur.execute("select avg(end - start) from kernels where name like ?", (f"%k_poisson<{a.k},%",)).fetchone()
+        if row and row[0]:
+            launch_us = row[0] / 1e3
 need = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU")
 missing = [c for c in need if c not in vals]
 if missing:
@@ -38,6 +47,8 @@ if missing:
 entry = {"read_bytes": int(2 * vals["FETCH_SIZE"][0] * 1024), "write_bytes": int(vals["WRITE_SIZE"][0] * 1024),
          "insts_valu": int(vals["SQ_INSTS_VALU"][0]), "launches": vals["SQ_INSTS_VALU"][1],
          "grid": list(a.grid), "kernel_hash": poisson_kernel_hash(), "round": a.round}
+if launch_us:
+    entry["launch_us"] = round(launch_us, 3)
 for extra in ("SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"):
     if extra in vals:
         entry[extra.lower()] = int(vals[extra][0])
