@@ -64,6 +64,12 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
         stream = int(rng.integers(-1, 2))
         full = int(rng.integers(0, 2))
         count = int(rng.integers(1, 3 * max(K, 3) + 2))
+        # whole runs of passes in one launch (grids whose tiles fit on chip): on or off, frame width, tile shape
+        small = int(rng.integers(0, 2))
+        s_halo = int(rng.choice([0, 0, 1, 2, 3, 5, 8, 12]))
+        s_cols, s_rows = (int(rng.choice([0, 0, 2, 3, 7, 16, 40, 200])) for _ in range(2))
+        if small and rng.random() < 0.6:
+            count += int(rng.integers(8, 30))
         scale, zero_frac = [(1.0, 0.0), (1.0, 0.0), (1e-2, 0.0), (1.0, 0.5), (1e-200, 0.0), (1e-300, 0.2), (1e-310, 0.3),
                             (1e200, 0.0), (1e300, 0.0)][int(rng.integers(0, 9))]
         p = ns_params("NavierStokes", nx=nx, ny=nyg)
@@ -94,7 +100,8 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
         wdP = np.asfortranarray(dP0[:, lo:hi - 2])
         nyw = hi - lo
         for opt, v in (("poisson_k", K), ("poisson_rows", rows), ("poisson_edge_percent", edge), ("poisson_xcd", xcd),
-                       ("poisson_stream", stream)):
+                       ("poisson_stream", stream), ("poisson_small", small), ("poisson_small_halo", s_halo),
+                       ("poisson_small_cols", s_cols), ("poisson_small_rows", s_rows)):
             ctx.set_option(opt, v)
         if pitched:
             ld = _pitch(nx)
@@ -139,15 +146,17 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
             ok = ok and strict_same(gPr[:, -1], wPr[:, -1])
         desc = (f"case {case}: nx={nx} nyg={nyg} window=[{lo},{hi}) pitched={pitched} K={K}->{ctx.get_option('poisson_k')} rows={rows} "
                 f"edge={edge} xcd={xcd} stream={stream} full={full} count={count} scale={scale} zeros={zero_frac} div={ctx.get_option('poisson_div_used')} "
-                f"edges_first={ef}")
+                f"edges_first={ef} one_launch={small} frame={s_halo} tile={s_cols}x{s_rows}")
         if not ok:
             bad += 1
             failures.append(desc)
             print("MISMATCH", desc, flush=True)
         elif verbose and case % 25 == 0:
             print("ok", desc, f"[{time.time() - t_start:.0f} s]", flush=True)
-    for opt in ("poisson_k", "poisson_rows", "poisson_edge_percent", "poisson_edge_task_rows"):
+    for opt in ("poisson_k", "poisson_rows", "poisson_edge_percent", "poisson_edge_task_rows", "poisson_small_halo",
+                "poisson_small_cols", "poisson_small_rows"):
         ctx.set_option(opt, 0)
+    ctx.set_option("poisson_small", 1)
     ctx.set_option("poisson_xcd", 1)
     ctx.set_option("poisson_stream", -1)
     if verbose:
