@@ -86,6 +86,11 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *                          "poisson_rows_used" read back the run's length and the tile height then.  A
  *                          wait between workgroups that runs out of polls ends the launch; the next
  *                          nsk_sync / nsk_download / residual of the context returns NSK_ERR_TIMEOUT.
+ *                          The workgroups of such a launch must be resident together: launches of
+ *                          different contexts of one process are chained on the device (an event wait,
+ *                          no host wait); another PROCESS that runs the same kind of launch on the same
+ *                          device at the same time can starve both until the polls run out -- switch
+ *                          the option off where several processes share a device.
  *   "poisson_small_halo"   passes between two hand-overs = width of a tile's frame (0 = 8)
  *   "poisson_small_cols", "poisson_small_rows"  tile of a workgroup (0 = the smallest square tiles that
  *                          cover the grid with no more workgroups than compute units)

@@ -23,6 +23,9 @@
 // All workgroups of a launch wait for each other, so they must be resident together: there are at most
 // as many as compute units.  Every spin is bounded; one that runs out raises an error word that the
 // next synchronising call of the context reports.
+#include <map>
+#include <mutex>
+
 #include "ns_poisson_kernel.h"
 
 namespace nsk_poisson {
@@ -310,13 +313,35 @@ int launch_one(nsk_ctx *ctx, const SmallArgs &A, size_t lds_bytes) {
   NSK_LAUNCH_CHECK();
   return 0;
 }
+// Two of these launches side by side on one device could each hold a part of the compute units and wait for
+// workgroups that find no room (until the poll limits end both with an error).  Within a process they are
+// therefore chained: a launch on another stream than the last one's waits for that one's end.  (Launches of
+// other processes on the same device cannot be seen from here.)
+struct LastLaunch {
+  hipEvent_t done = nullptr;
+  hipStream_t stream = nullptr;
+  bool any = false;
+};
+std::mutex g_chain_mu;
+std::map<int, LastLaunch> g_chain;  // by device
+
 template <int DIV>
 int launch_small(nsk_ctx *ctx, const SmallArgs &A, int slots) {
   NSK_REQUIRE(slots >= 1 && slots <= MAXM, "small-grid Poisson launch: %d cell slots per thread (1..%d)", slots, MAXM);
   const size_t lds_bytes = 2 * (size_t)BUF + 16;
-  if (slots == 1) return launch_one<DIV, 1>(ctx, A, lds_bytes);
-  if (slots == 2) return launch_one<DIV, 2>(ctx, A, lds_bytes);
-  return launch_one<DIV, 4>(ctx, A, lds_bytes);
+  std::lock_guard<std::mutex> lock(g_chain_mu);
+  LastLaunch &last = g_chain[ctx->device];
+  if (!last.done) NSK_HIP(hipEventCreateWithFlags(&last.done, hipEventDisableTiming));
+  if (last.any && last.stream != ctx->stream) NSK_HIP(hipStreamWaitEvent(ctx->stream, last.done, 0));
+  int rc;
+  if (slots == 1) rc = launch_one<DIV, 1>(ctx, A, lds_bytes);
+  else if (slots == 2) rc = launch_one<DIV, 2>(ctx, A, lds_bytes);
+  else rc = launch_one<DIV, 4>(ctx, A, lds_bytes);
+  if (rc) return rc;
+  NSK_HIP(hipEventRecord(last.done, ctx->stream));
+  last.stream = ctx->stream;
+  last.any = true;
+  return 0;
 }
 
 }  // namespace

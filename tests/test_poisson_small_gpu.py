@@ -168,3 +168,42 @@ def test_a_workgroup_that_never_arrives_ends_in_an_error(ctx):
     ctx.set_option("poisson_small", 0)
     got = run_gpu(ctx, p, Pr0, dP0, dv, 40, 0, True)
     assert same_bits(want[0], got[0]) and same_bits(want[1], got[1])
+
+
+def test_two_contexts_on_two_streams_side_by_side(oracle):
+    """The workgroups of a one-launch run wait for each other, so two such launches side by side could starve
+    each other of compute units; within a process the library chains them on the device.  Two contexts on
+    two streams, launches queued alternately with no host wait in between: both give the oracle's bits."""
+    import ctypes as C
+    import torch
+    from navierstokes_amd import _lib
+    from navierstokes_amd.ns import _pitch, c_params
+    from util import Dev
+    nx, ny, count = 153, 255, 60
+    p = ns_params("NavierStokes")
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ctxs = [_lib.Context(0, st.cuda_stream) for st in streams]
+    try:
+        cases = []
+        for i, k in enumerate(ctxs):
+            Pr0, dP0, dv = fields(nx, ny, 70 + i)
+            ld = _pitch(nx)
+            emb = np.full((nx, ny), np.nan, order="F")
+            emb[1:-1, 1:-1] = dP0
+            dev = (Dev(Pr0, ld, pad_value=np.nan), Dev(emb, ld, pad_value=np.nan), Dev(dv, ld, pad_value=np.nan))
+            Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
+            oracle_iters(oracle, p, Pr, dP, dv, 3 * count, 0)
+            cases.append((k, dev, Pr, dP))
+        torch.cuda.synchronize()
+        cp = c_params(p, ld_pr=_pitch(nx), dp_embedded=1)
+        for _ in range(3):
+            for k, dev, _, _ in cases:
+                k.ns_poisson_iters(dev[0].ptr, dev[1].ptr, dev[2].ptr, C.byref(cp), count)
+        for k, dev, Pr, dP in cases:
+            k.sync()
+            assert k.get_option("poisson_k") == count
+            assert same_bits(dev[0].get(), Pr)
+            assert same_bits(np.asfortranarray(dev[1].get()[1:-1, 1:-1]), dP)
+    finally:
+        for k in ctxs:
+            k.close()
