@@ -79,7 +79,7 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *                          by the next exact one (2 -> 3 -> 4 -> IEEE)
  *   "poisson_div_used"     (read only) the form the last fused Poisson call ran
  *   "poisson_small"        nsk_ns_poisson_iters on whole domains whose tiles fit on chip (up to 256 tiles of up
- *                          to 4096 cells with their frames; 153 x 255 uses 209), runs of 12 passes or
+ *                          to 6144 cells with their frames; 153 x 255 uses 209), runs of 12 passes or
  *                          more: 1 = the whole run in one launch, the fields in LDS and registers, tiles
  *                          handing their outer cells to their neighbours every "poisson_small_halo"
  *                          passes (default), 0 = launches of "poisson_k" passes.  "poisson_k" and

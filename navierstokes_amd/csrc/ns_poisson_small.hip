@@ -33,8 +33,7 @@ namespace nsk_poisson {
 namespace {
 
 constexpr int NT = 1024;         // threads per workgroup
-constexpr int MAXM = 4;          // cell slots per thread (more would spill registers at 1024 threads)
-constexpr int BUF = NT * MAXM * 8;  // bytes from one LDS copy to the other
+constexpr int MAXM = 6;          // cell slots per thread (the register budget of 1024 threads is 128 each: eight slots spill)
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 enum { F_BAD = 0, F_ERR = 1, F_WORDS = 4 };  // words behind the progress words
 
@@ -88,6 +87,7 @@ enum {
 template <int DIV, int M>
 __global__ void __launch_bounds__(NT) k_poisson_small(SmallArgs A) {
   extern __shared__ __attribute__((aligned(16))) char lds[];  // copy 0 | copy 1 | one flag word
+  constexpr int BUF = NT * M * 8;                             // bytes from one LDS copy to the other
   const int tid = threadIdx.x, g = blockIdx.x;
   const int nx = A.nx, ny = A.ny, ld = A.ld, H = A.H;
   const int gx = g % A.GX, gy = g / A.GX;
@@ -158,11 +158,18 @@ __global__ void __launch_bounds__(NT) k_poisson_small(SmallArgs A) {
   // readers of those cells -- have completed stage 1.
   const double *pr_src = A.mode == 1 ? A.pr_out : A.pr_in, *dp_src = A.mode == 1 ? A.dp_out : A.dp_in;
   // ---- this thread's cells ------------------------------------------------------------------------------
-  // ac / adn / aup: byte offsets in an LDS copy of the cell's left neighbour, of the cell below and the cell
-  // above; gi / di: the cell in the global arrays; dep: the last pass of a block in which the cell is still
-  // valid (its distance from the frame's rim; no limit towards the rim of the grid; 0 = never computed)
-  int ac[M], adn[M], aup[M], gi[M], di[M], dep[M], fl[M];
+  // ac: byte offset in an LDS copy of the cell's left neighbour (the cell below / above: see dn / up); gi: the
+  // cell in the global arrays; df = 1024 * dep + kind, dep = the last pass of a block in which the cell is
+  // still valid (its distance from the frame's rim; no limit towards the rim of the grid; 0 = never computed).
+  // With more than four slots the offsets of the cells below and above are formed when needed (two additions
+  // per cell and pass) instead of kept: 128 registers per thread have to do.
+  constexpr bool KEEP = M <= 4;
+  int ac[M], adn[KEEP ? M : 1], aup[KEEP ? M : 1], gi[M], df[M];
   double dP[M], gg[M];
+  const int below = (1 - W) * 8, above = (1 + W) * 8;
+  auto dn = [&](int m) { return KEEP ? adn[m] : ac[m] + below; };
+  auto up = [&](int m) { return KEEP ? aup[m] : ac[m] + above; };
+  auto dp_of = [&](int g_index) { return dp_index(g_index % ld, g_index / ld); };
   int emin = 0;
   bool nonfin = false;
   auto note = [&](double x) {
@@ -171,7 +178,7 @@ __global__ void __launch_bounds__(NT) k_poisson_small(SmallArgs A) {
       nonfin |= non_finite(x);
     }
   };
-  constexpr int FAR = 1 << 30;
+  constexpr int FAR = 1 << 20;
 #pragma unroll
   for (int m = 0; m < M; m++) {
     const int e = tid + NT * m;
@@ -182,14 +189,14 @@ __global__ void __launch_bounds__(NT) k_poisson_small(SmallArgs A) {
     const bool edge = owned && ((gx > 0 && c < oc_lo + H) || (gx + 1 < A.GX && c >= oc_hi - H) || (gy > 0 && r < or_lo + H) ||
                                 (gy + 1 < A.GY && r >= or_hi - H));
     const int q = l * W + cl;
-    ac[m] = (q - 1) * 8, adn[m] = (q - W) * 8, aup[m] = (q + W) * 8;
+    ac[m] = (q - 1) * 8;
+    if (KEEP) adn[m] = (q - W) * 8, aup[m] = (q + W) * 8;
     gi[m] = have ? r * ld + c : 0;
-    di[m] = inner ? dp_index(c, r) : 0;
     const int d = min(min(ec_lo > 0 ? cl : FAR, ec_hi < nx ? W - 1 - cl : FAR), min(er_lo > 0 ? l : FAR, er_hi < ny ? ER - 1 - l : FAR));
-    dep[m] = inner ? d : 0;
-    fl[m] = (have ? HAVE : 0) | (inner ? INNER : 0) | (owned ? OWNED : 0) | (edge ? EDGE : 0) | (inner && c == 1 ? C_FIRST : 0) |
+    const int kind = (have ? HAVE : 0) | (inner ? INNER : 0) | (owned ? OWNED : 0) | (edge ? EDGE : 0) | (inner && c == 1 ? C_FIRST : 0) |
             (inner && c == nx - 2 ? C_LAST : 0) | (inner && r == 1 ? R_FIRST : 0) | (inner && r == ny - 2 ? R_LAST : 0) |
             (r < A.xbc_rows ? XBC : 0);
+    df[m] = (inner ? d : 0) * 1024 + kind;
     dP[m] = gg[m] = 0.0;
     if (have) {
       const double v = pr_src[gi[m]];
@@ -197,7 +204,7 @@ __global__ void __launch_bounds__(NT) k_poisson_small(SmallArgs A) {
       note(v);
     }
     if (inner) {
-      dP[m] = dp_src[di[m]];
+      dP[m] = dp_src[dp_index(c, r)];
       gg[m] = A.rho_dt * A.divv[gi[m]];
     }
   }
@@ -209,11 +216,11 @@ __global__ void __launch_bounds__(NT) k_poisson_small(SmallArgs A) {
   auto pass = [&](int s, const int RD, const int WR) {
 #pragma unroll
     for (int m = 0; m < M; m++) {
-      if (s <= dep[m]) {
+      if (s * 1024 <= df[m]) {  // (s <= dep: the kind bits are below 1024)
         const int k = ac[m];
-        const double lft = at(RD + k), cen = at(RD + k + 8), rgt = at(RD + k + 16), dn = at(RD + adn[m]), up = at(RD + aup[m]);
+        const double lft = at(RD + k), cen = at(RD + k + 8), rgt = at(RD + k + 16), low = at(RD + dn(m)), upp = at(RD + up(m));
         const double d2x = (rgt - cen) - (cen - lft);
-        const double d2y = (up - cen) - (cen - dn);
+        const double d2y = (upp - cen) - (cen - low);
         const double qx = div_const<DIV>(div_const<DIV>(d2x, A.dx, A.rdx_h, A.rdx_l), A.dx, A.rdx_h, A.rdx_l);
         const double qy = div_const<DIV>(div_const<DIV>(d2y, A.dy, A.rdy_h, A.rdy_l), A.dy, A.rdy_h, A.rdy_l);
         const double L = qx + qy - gg[m];
@@ -224,20 +231,20 @@ __global__ void __launch_bounds__(NT) k_poisson_small(SmallArgs A) {
         at(WR + k + 8) = pnew;
         // set_bc_Pr!: bc_x! (rows below its limit take their inner neighbour's new value, the others
         // keep theirs), then bc_yval! (bottom row = the row above it as bc_x! left it, top row = val)
-        const int f = fl[m];
+        const int f = df[m];
         if (f & BC_ANY) {
           const double left = (f & XBC) ? pnew : lft, right = (f & XBC) ? pnew : rgt;
           if (f & C_FIRST) at(WR + k) = left;
           if (f & C_LAST) at(WR + k + 16) = right;
           if (f & R_FIRST) {
-            at(WR + adn[m]) = pnew;
-            if (f & C_FIRST) at(WR + adn[m] - 8) = left;
-            if (f & C_LAST) at(WR + adn[m] + 8) = right;
+            at(WR + dn(m)) = pnew;
+            if (f & C_FIRST) at(WR + dn(m) - 8) = left;
+            if (f & C_LAST) at(WR + dn(m) + 8) = right;
           }
           if (f & R_LAST) {
-            at(WR + aup[m]) = A.topval;
-            if (f & C_FIRST) at(WR + aup[m] - 8) = A.topval;
-            if (f & C_LAST) at(WR + aup[m] + 8) = A.topval;
+            at(WR + up(m)) = A.topval;
+            if (f & C_FIRST) at(WR + up(m) - 8) = A.topval;
+            if (f & C_LAST) at(WR + up(m) + 8) = A.topval;
           }
         }
       }
@@ -264,9 +271,9 @@ __global__ void __launch_bounds__(NT) k_poisson_small(SmallArgs A) {
     const int CUR = cur ? BUF : 0;
 #pragma unroll
     for (int m = 0; m < M; m++) {
-      if (fl[m] & EDGE) {
+      if (df[m] & EDGE) {
         __hip_atomic_store(x_pr + gi[m], at(CUR + ac[m] + 8), RLX, AGENT);
-        if (fl[m] & INNER) __hip_atomic_store(x_dp + gi[m], dP[m], RLX, AGENT);
+        if (df[m] & INNER) __hip_atomic_store(x_dp + gi[m], dP[m], RLX, AGENT);
       }
     }
     publish(exchanges + 2);
@@ -283,10 +290,10 @@ __global__ void __launch_bounds__(NT) k_poisson_small(SmallArgs A) {
     }
 #pragma unroll
     for (int m = 0; m < M; m++) {
-      if ((fl[m] & (HAVE | OWNED)) == HAVE) {
+      if ((df[m] & (HAVE | OWNED)) == HAVE) {
         at(CUR + ac[m] + 8) = hp[m];
         note(hp[m]);
-        if (fl[m] & INNER) dP[m] = hd[m];
+        if (df[m] & INNER) dP[m] = hd[m];
       }
     }
     __syncthreads();
@@ -297,9 +304,9 @@ __global__ void __launch_bounds__(NT) k_poisson_small(SmallArgs A) {
   const int CUR = cur ? BUF : 0;
 #pragma unroll
   for (int m = 0; m < M; m++) {
-    if (fl[m] & OWNED) {
+    if (df[m] & OWNED) {
       A.pr_out[gi[m]] = at(CUR + ac[m] + 8);
-      if (fl[m] & INNER) A.dp_out[di[m]] = dP[m];
+      if (df[m] & INNER) A.dp_out[dp_of(gi[m])] = dP[m];
     }
   }
   if (DIV != DIV_IEEE && (emin < E_MIN_OK || nonfin)) __hip_atomic_store(A.words + G + F_BAD, 1u, RLX, AGENT);
@@ -307,7 +314,8 @@ __global__ void __launch_bounds__(NT) k_poisson_small(SmallArgs A) {
 }
 
 template <int DIV, int M>
-int launch_one(nsk_ctx *ctx, const SmallArgs &A, size_t lds_bytes) {
+int launch_one(nsk_ctx *ctx, const SmallArgs &A) {
+  const size_t lds_bytes = 2 * (size_t)NT * M * 8 + 16;
   NSK_HIP(nsk_allow_lds(ctx, (const void *)k_poisson_small<DIV, M>, lds_bytes));
   k_poisson_small<DIV, M><<<A.GX * A.GY, NT, lds_bytes, ctx->stream>>>(A);
   NSK_LAUNCH_CHECK();
@@ -328,15 +336,15 @@ std::map<int, LastLaunch> g_chain;  // by device
 template <int DIV>
 int launch_small(nsk_ctx *ctx, const SmallArgs &A, int slots) {
   NSK_REQUIRE(slots >= 1 && slots <= MAXM, "small-grid Poisson launch: %d cell slots per thread (1..%d)", slots, MAXM);
-  const size_t lds_bytes = 2 * (size_t)BUF + 16;
   std::lock_guard<std::mutex> lock(g_chain_mu);
   LastLaunch &last = g_chain[ctx->device];
   if (!last.done) NSK_HIP(hipEventCreateWithFlags(&last.done, hipEventDisableTiming));
   if (last.any && last.stream != ctx->stream) NSK_HIP(hipStreamWaitEvent(ctx->stream, last.done, 0));
   int rc;
-  if (slots == 1) rc = launch_one<DIV, 1>(ctx, A, lds_bytes);
-  else if (slots == 2) rc = launch_one<DIV, 2>(ctx, A, lds_bytes);
-  else rc = launch_one<DIV, 4>(ctx, A, lds_bytes);
+  if (slots == 1) rc = launch_one<DIV, 1>(ctx, A);
+  else if (slots == 2) rc = launch_one<DIV, 2>(ctx, A);
+  else if (slots <= 4) rc = launch_one<DIV, 4>(ctx, A);
+  else rc = launch_one<DIV, 6>(ctx, A);
   if (rc) return rc;
   NSK_HIP(hipEventRecord(last.done, ctx->stream));
   last.stream = ctx->stream;
@@ -357,7 +365,7 @@ bool small_grid_applies(const nsk_ctx *ctx, const nsk_ns_params *p, int count, S
   // is a frame of H/2 more cells per pass on average.  The smallest tiles that cover the grid with no more
   // workgroups than compute units are taken: the passes are bound by the arithmetic of one compute unit.
   for (int h : {ctx->poisson_small_halo > 0 ? ctx->poisson_small_halo : 8, 6, 4}) {
-    for (int t = h; t <= 4096; t += (t < 32 ? 2 : 8)) {
+    for (int t = h; t <= 4096; t += (t < 128 ? 2 : 16)) {
       int tc = ctx->poisson_small_cols > 0 ? ctx->poisson_small_cols : t;
       int tr = ctx->poisson_small_rows > 0 ? ctx->poisson_small_rows : t;
       int hh = h;
