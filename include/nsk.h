@@ -82,7 +82,8 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *                          to 6144 cells with their frames; 153 x 255 uses 209), runs of 12 passes or
  *                          more: 1 = the whole run in one launch, the fields in LDS and registers, tiles
  *                          handing their outer cells to their neighbours every "poisson_small_halo"
- *                          passes (default), 0 = launches of "poisson_k" passes.  "poisson_k" and
+ *                          passes (default), 0 = launches of "poisson_k" passes (as does a "poisson_k" or
+ *                          "poisson_rows" other than 0: the caller has pinned that plan).  "poisson_k" and
  *                          "poisson_rows_used" read back the run's length and the tile height then.  A
  *                          wait between workgroups that runs out of polls ends the launch; the next
  *                          nsk_sync / nsk_download / residual of the context returns NSK_ERR_TIMEOUT.

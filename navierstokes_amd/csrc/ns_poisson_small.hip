@@ -357,6 +357,7 @@ int launch_small(nsk_ctx *ctx, const SmallArgs &A, int slots) {
 // Is the one-launch form the one for this call, and with which tiles?  Whole domains only.
 bool small_grid_applies(const nsk_ctx *ctx, const nsk_ns_params *p, int count, SmallPlan *plan) {
   if (!ctx->poisson_small || p->iy0 != 0 || p->ny != p->nyg || count < 12) return false;
+  if (ctx->poisson_k != 0 || ctx->poisson_rows != 0) return false;  // the caller has pinned the launch-per-K-passes plan
   const int nx = p->nx, ny = p->ny;
   if (nx < 3 || ny < 3) return false;
   const int cus = ctx->num_simds / 4;
