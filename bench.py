@@ -375,6 +375,22 @@ def main():
                              "poisson_iters": its, "seconds": secs,
                              "us_per_pass_whole_step": [s_ / i * 1e6 for s_, i in zip(secs, its)],
                              "from": "reference initial condition"}
+        # the reference's own CPU-runnable configuration (scripts/NavierStokes.jl as shipped, 153 x 255): its
+        # fields fit on chip, so the passes between two residual checks run as one launch; the same steps with
+        # a launch per K passes beside it
+        ps = ns_params("NavierStokes")
+        small = {"grid": [ps.nx, ps.ny], "from": "reference initial condition", "steps": 4}
+        for key, one_launch in (("one_launch_per_run_of_passes", 1), ("launch_per_k_passes", 0)):
+            sim = NavierStokes(ps, device=f"cuda:{local}")
+            sim.ctx.set_option("poisson_small", one_launch)
+            sim.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            its = [sim.step() for _ in range(small["steps"])]
+            torch.cuda.synchronize()
+            ts = time.perf_counter() - t0
+            small[key] = {"steps_per_s": small["steps"] / ts, "us_per_pass_whole_step": ts / sum(its) * 1e6, "poisson_iters": its}
+        out["time_steps_default_grid"] = small
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(p1, a.cpu_seconds)
     if rank == 0:

@@ -50,6 +50,11 @@ def test_single_gpu_line():
     assert "passes" in c["sample"]
     t = j["time_steps"]
     assert t["steps"] == 1 and t["poisson_iters"][0] % 10232 == 0 and t["steps_per_s"] > 0
+    # the reference's own default grid, both forms of the Poisson passes: same pass counts, the one-launch form faster
+    d = j["time_steps_default_grid"]
+    a, b = d["one_launch_per_run_of_passes"], d["launch_per_k_passes"]
+    assert d["grid"] == [153, 255] and a["poisson_iters"] == b["poisson_iters"] and all(i % 152 == 0 for i in a["poisson_iters"])
+    assert 0 < a["us_per_pass_whole_step"] < b["us_per_pass_whole_step"]
 
 
 def test_two_rank_line_as_the_driver_launches_it():
