@@ -97,6 +97,12 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *                          cover the grid with no more workgroups than compute units)
  *   "poisson_small_spin_limit"  polls before a workgroup gives up on a neighbour (0 = 2^22)
  *   "poisson_small_test_absent" testing: 1 + the workgroup that leaves at once (0 = none)
+ *   "poisson_pairs"        launches of "poisson_k" passes on pitched storage: 1 = the tasks of a column strip in
+ *                          pairs that start at a common row and walk away from it, one up and one down the
+ *                          array, handing each other that row's values of every pass through LDS, so that
+ *                          neither recomputes halo rows at that end (default; 5-7 % faster at 2559 x 4095),
+ *                          0 = every task with halo rows at both ends, 2 = the launch shape of 1 without
+ *                          pairs (for timing).  NSK_POISSON_PAIRS in the environment sets the default.
  *   "poisson_tall_percent" launches of "poisson_k" passes: interior tasks in pairs of
  *                          poisson_rows * (100 +- this) / 100 rows that start together, so that the last
  *                          round of tasks ends evenly (0 = all alike, the default: at most 2 % gained)

@@ -351,7 +351,10 @@ int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double 
 
   // Passes per launch and task shape: forced by the options, otherwise the cheapest by the
   // planner's estimate for this grid.
-  const int ep = ctx->poisson_edge_percent;
+  // (with the interior tasks in pairs -- halo rows at one end only -- the tasks of the two rim strips, which
+  //  keep theirs at both ends, are cut shorter still: 62 % of the interior height instead of 75)
+  const bool pairs_likely = aligned && ctx->poisson_pairs && !ctx->no_alloc_call && !ef && (div == DIV_FMA2 || div == DIV_IEEE);
+  const int ep = ctx->poisson_edge_percent > 0 ? ctx->poisson_edge_percent : (pairs_likely ? 62 : 0);
   const TaskPlan top = choose_plan(nx, ny, ctx->num_simds, aligned, ctx->poisson_k, count < 8 ? count : 8,
                                    ctx->poisson_rows, ep);
   const int kmax = top.K;
@@ -526,7 +529,10 @@ extern "C" int nsk_ns_poisson_iters_static(nsk_ctx *ctx, double *Pr, double *dPr
     NSK_HIP(hipMemsetAsync(part_pr, 0, elems * sizeof(double), ctx->stream));
     NSK_HIP(hipMemsetAsync(part_dp, 0, elems * sizeof(double), ctx->stream));
   }
-  return iters_with_partners(ctx, Pr, dPrdtau, divV, p, count, part_pr, part_dp);
+  ctx->no_alloc_call = true;  // (the paired tasks keep their task list in device memory)
+  const int rc = iters_with_partners(ctx, Pr, dPrdtau, divV, p, count, part_pr, part_dp);
+  ctx->no_alloc_call = false;
+  return rc;
 }
 
 extern "C" int nsk_division_form(double d, int *form_out, double *rh_out, double *rl_out) {

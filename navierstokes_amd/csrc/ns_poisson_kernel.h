@@ -1,6 +1,10 @@
 // Multi-pass Poisson kernel (templates).  Included by ns_poisson.hip (host logic) and by
 // ns_poisson_inst.hip, which is compiled once per passes-per-launch value K.
 #pragma once
+#include <algorithm>
+#include <utility>
+#include <vector>
+
 #include "nsk_internal.h"
 
 // Build-time shape of the staged input path: rows requested ahead of the row in use, and
@@ -106,7 +110,7 @@ __device__ __forceinline__ double lane_next(double x) {
 }
 
 template <bool ALIGNED>
-__device__ __forceinline__ void load_pair(const double *__restrict__ p, size_t off, bool m0,
+__device__ __forceinline__ void load_pair(const double *__restrict__ p, ptrdiff_t off, bool m0,
                                           bool m1, double &v0, double &v1) {
   if (ALIGNED) {
     if (m0 || m1) {
@@ -124,7 +128,7 @@ __device__ __forceinline__ void load_pair(const double *__restrict__ p, size_t o
 }
 
 template <bool ALIGNED>
-__device__ __forceinline__ void store_pair(double *__restrict__ p, size_t off, bool m0, bool m1,
+__device__ __forceinline__ void store_pair(double *__restrict__ p, ptrdiff_t off, bool m0, bool m1,
                                            double v0, double v1) {
   if (ALIGNED) {
     if (m0 || m1) *reinterpret_cast<double2 *>(p + off) = make_double2(v0, v1);
@@ -188,7 +192,12 @@ struct DmaGeometry {
   static constexpr int LDS_BYTES = (2 * NST + NSG) * 1024;
 };
 
-template <int K, bool ALIGNED, int DIV, bool EDGE, bool STREAM = false>
+// PAIR: the task is one of two that start at a common row and walk away from it, one up and one down the
+// array (the second with negative row strides: in its own row numbers it walks up as well).  Neither needs
+// halo rows at the common end: where a pass first works on the task's first row, the row "below" it is the
+// partner's first row of the same pass, handed over through LDS (one exchange per pass, in the first K
+// steps), instead of K rows that both would recompute.
+template <int K, bool ALIGNED, int DIV, bool EDGE, bool STREAM = false, bool PAIR = false>
 struct Task {
   static constexpr int HK = (K + 1) & ~1;    // column halo, even so that pairs stay aligned
   static constexpr int WOUT = 128 - 2 * HK;  // columns a strip produces
@@ -202,13 +211,18 @@ struct Task {
   const PoissonArgs &A;
   double2 *lds;  // register path: ∇V ring [RING][64]; DMA path: the three staging rings
   int lane, c0, r0, r1, jstart, jend;
+  int jtop;  // PAIR: last row that arrives in a steady step (below the window's top rows, if the task reaches them)
   bool indom[2], inter[2], outcol[2];
   const double *__restrict__ prs;
   const double *__restrict__ dvs;
   const double *__restrict__ dps;
   double *__restrict__ dpd;
   double *__restrict__ prd;
-  size_t ld, ldd;
+  ptrdiff_t ld, ldd;  // row strides, negative for a task that walks down the array
+  int nyt;            // rows of the window in the task's row numbers (no limit for a task that walks down)
+  bool pb, pt;        // row 0 / row nyt-1 of the task's numbering is the window's physical bottom / top
+  unsigned xch;       // PAIR: LDS byte address of the exchange area, and which of the two this wavefront is
+  int wave;
   size_t cc;          // DMA path: this lane's column, clamped into the row
   unsigned lds_lane;  // DMA path: LDS byte address of this lane's 16 bytes in slot 0
 
@@ -217,14 +231,31 @@ struct Task {
   bool bad_out;   // a stored output was Inf or NaN
   double LP[NSLOT][2], LD[NSLOT][2], LG[NSLOT][2];  // register path: rows in flight
 
-  __device__ __forceinline__ Task(const PoissonArgs &a, double2 *shared, int sx, int row0, int row1)
+  // Rows [row0, row1) of the window.  mirror >= 0 (= row1 - 1): the task walks DOWN from window row `mirror`
+  // to row0; in its own numbering window row r is row 2*mirror + 1 - r, so its first row has the number
+  // mirror + 1 -- the number of the first row of its partner, which walks up from there.
+  __device__ __forceinline__ Task(const PoissonArgs &a, double2 *shared, int sx, int row0, int row1, int mirror = -1,
+                                  unsigned exchange = 0, int which = 0)
       : A(a), lds(shared) {
     lane = threadIdx.x & 63;
     c0 = sx * WOUT - HK + 2 * lane;
-    r0 = row0;
-    r1 = row1;
-    jstart = max(r0 - K, 0);
-    jend = min(r1 - 1 + K, A.ny - 1);
+    xch = exchange;
+    wave = which;
+    if (mirror >= 0) {  // window row r <-> task row 2*mirror + 1 - r
+      r0 = mirror + 1;
+      r1 = 2 * mirror + 2 - row0;
+      nyt = 1 << 30;
+      pb = pt = false;
+    } else {
+      r0 = row0;
+      r1 = row1;
+      nyt = A.ny;
+      pb = A.phys_bottom != 0;
+      pt = A.phys_top != 0;
+    }
+    jstart = PAIR ? r0 : max(r0 - K, 0);
+    jend = min(r1 - 1 + K, nyt - 1);
+    jtop = pt ? nyt - 2 : 0x7fffffff;
 #pragma unroll
     for (int v = 0; v < 2; v++) {
       const int c = c0 + v;
@@ -235,13 +266,19 @@ struct Task {
       const int owner_c = c == A.nx - 1 ? A.nx - 2 : c;
       outcol[v] = indom[v] && owner_c >= sx * WOUT && owner_c < (sx + 1) * WOUT;
     }
-    ld = (size_t)A.ld;
-    ldd = (size_t)A.ldd;
+    ld = (ptrdiff_t)A.ld;
+    ldd = (ptrdiff_t)A.ldd;
     prs = A.pr_src;
     dvs = A.divv;
     dps = A.dp_embedded ? A.dp_src : A.dp_src - ldd - 1;  // addressed by Pr cell coordinates
     dpd = A.dp_embedded ? A.dp_dst : A.dp_dst - ldd - 1;
     prd = A.pr_dst;
+    if (mirror >= 0) {  // task row j is window row 2*mirror + 1 - j: bases at that row 0, strides negated
+      const ptrdiff_t top = 2 * (ptrdiff_t)mirror + 1;
+      prs += top * ld, dvs += top * ld, prd += top * ld;
+      dps += top * ldd, dpd += top * ldd;
+      ld = -ld, ldd = -ldd;
+    }
     // Lanes outside the domain fetch some pair inside the row: their values are never used
     // (such cells are carried through and not stored), the clamp only keeps the access legal.
     cc = (size_t)min(max(c0, 0), A.ld - 2);
@@ -265,11 +302,11 @@ struct Task {
 
   // ---- register path ---------------------------------------------------------------------
   __device__ __forceinline__ void load_row(int j, int slot) {
-    const bool rowint = j >= 1 && j <= A.ny - 2;
-    load_pair<ALIGNED>(prs, (size_t)j * ld + c0, indom[0], indom[1], LP[slot][0], LP[slot][1]);
-    load_pair<false>(dps, (size_t)j * ldd + c0, rowint && inter[0], rowint && inter[1], LD[slot][0],
+    const bool rowint = j >= 1 && j <= nyt - 2;
+    load_pair<ALIGNED>(prs, (ptrdiff_t)j * ld + c0, indom[0], indom[1], LP[slot][0], LP[slot][1]);
+    load_pair<false>(dps, (ptrdiff_t)j * ldd + c0, rowint && inter[0], rowint && inter[1], LD[slot][0],
                      LD[slot][1]);
-    load_pair<ALIGNED>(dvs, (size_t)j * ld + c0, rowint && indom[0], rowint && indom[1],
+    load_pair<ALIGNED>(dvs, (ptrdiff_t)j * ld + c0, rowint && indom[0], rowint && indom[1],
                        LG[slot][0], LG[slot][1]);
   }
 
@@ -281,7 +318,7 @@ struct Task {
   // host's decision (stream_inputs).
   __device__ __forceinline__ void dma_row(int j, int sp, int sg) {
     constexpr int AUX = STREAM ? 2 : 0;
-    const size_t off = (size_t)j * ld + cc;
+    const ptrdiff_t off = (ptrdiff_t)j * ld + (ptrdiff_t)cc;
     char *base = reinterpret_cast<char *>(lds);
     __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(prs + off), (lds_void_t *)(base + sp * 1024), 16, 0, AUX);
     __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(dps + off), (lds_void_t *)(base + (NST + sp) * 1024), 16, 0, AUX);
@@ -363,10 +400,10 @@ struct Task {
 
   __device__ __forceinline__ void store_dp(int r, const double dnew[2]) {
     if (ALIGNED)
-      store_pair<true>(dpd, (size_t)r * ldd + c0, outcol[0] && inter[0], outcol[1] && inter[1],
+      store_pair<true>(dpd, (ptrdiff_t)r * ldd + c0, outcol[0] && inter[0], outcol[1] && inter[1],
                        dnew[0], dnew[1]);
     else
-      store_pair<false>(dpd, (size_t)r * ldd + c0, outcol[0] && inter[0], outcol[1] && inter[1],
+      store_pair<false>(dpd, (ptrdiff_t)r * ldd + c0, outcol[0] && inter[0], outcol[1] && inter[1],
                         dnew[0], dnew[1]);
   }
 
@@ -389,7 +426,7 @@ struct Task {
       if (r >= jstart && r <= jend) {
         double pnew[2], dnew[2];
         const double *cen = P[s][PH], *up = P[s][PH ^ 1], *dq = D[s][PH];
-        if (r == jstart || r == jend) {
+        if ((r == jstart && !PAIR) || r == jend) {
           // Edge row of the task: carried through unchanged.  It is either a halo row
           // (recomputed by the neighbouring task) or a boundary row of the window.
 #pragma unroll
@@ -407,13 +444,31 @@ struct Task {
           // y: (u-c)-(c-d); c-d is the previous step's u-c
           double upd[2] = {up[0] - cen[0], up[1] - cen[1]};
           double low[2] = {E[s][0], E[s][1]};
+          if (PAIR && r == jstart) {
+            // The row below the task's first row is the partner's first row, at the same pass and in the same
+            // step: both hand theirs over.  (LDS write, wait for it, barrier of the two wavefronts, read; the
+            // slots alternate with the pass, so one barrier per exchange is enough.)
+            const unsigned slot = xch + (unsigned)(s & 1) * 2048u + 16u * (unsigned)lane;
+            const v4i_t mine = {__double2loint(cen[0]), __double2hiint(cen[0]), __double2loint(cen[1]), __double2hiint(cen[1])};
+            lds_write16(slot + (unsigned)wave * 1024u, mine);
+            lds_wait_all();
+            __builtin_amdgcn_s_barrier();
+            v4i_t theirs = lds_read16_nowait(slot + (unsigned)(wave ^ 1) * 1024u);
+            lds_wait_all();
+            pin_after_wait(theirs);
+            const double2 pc = as_double2(theirs);
+            const double below[2] = {pc.x, pc.y};
+            note_values<QD>(below);
+            low[0] = cen[0] - below[0];
+            low[1] = cen[1] - below[1];
+          }
           E[s][0] = upd[0];
           E[s][1] = upd[1];
           if (s >= 2) {
             // Inputs are pass >= 1 values: rows 0 / ny-1 of that pass hold the y boundary
             // conditions (bc_yval!), which the carried-through edge rows do not.
-            if (A.phys_bottom && r == 1) low[0] = low[1] = 0.0;  // Pr[ix,1] = Pr[ix,2]: c - d = +0
-            if (A.phys_top && r == A.ny - 2) {
+            if (pb && r == 1) low[0] = low[1] = 0.0;  // Pr[ix,1] = Pr[ix,2]: c - d = +0
+            if (pt && r == nyt - 2) {
               upd[0] = A.topval - cen[0];
               upd[1] = A.topval - cen[1];
             }
@@ -431,15 +486,15 @@ struct Task {
           }
         } else if (r >= r0 && r < r1) {
           note_stored<QD>(pnew);
-          const bool rowint = r >= 1 && r <= A.ny - 2;
-          const bool first = r == 0, last = r == A.ny - 1;
-          if (!(first && A.phys_bottom)) {
+          const bool rowint = r >= 1 && r <= nyt - 2;
+          const bool first = r == 0, last = r == nyt - 1;
+          if (!(first && pb)) {
             double o0 = pnew[0], o1 = pnew[1];
-            if (last && A.phys_top) o0 = o1 = A.topval;
-            store_pair<ALIGNED>(prd, (size_t)r * ld + c0, outcol[0], outcol[1], o0, o1);
+            if (last && pt) o0 = o1 = A.topval;
+            store_pair<ALIGNED>(prd, (ptrdiff_t)r * ld + c0, outcol[0], outcol[1], o0, o1);
           }
-          if (r == 1 && A.phys_bottom)  // bc_yval!: Pr[ix,1] = Pr[ix,2]
-            store_pair<ALIGNED>(prd, (size_t)c0, outcol[0], outcol[1], pnew[0], pnew[1]);
+          if (r == 1 && pb)  // bc_yval!: Pr[ix,1] = Pr[ix,2]
+            store_pair<ALIGNED>(prd, (ptrdiff_t)c0, outcol[0], outcol[1], pnew[0], pnew[1]);
           if (rowint) store_dp(r, dnew);
         }
       }
@@ -508,7 +563,7 @@ struct Task {
         }
       } else if (!DMA || r >= r0) {  // (the register path enters steady steps only once r >= r0)
         note_stored<QD>(pnew);
-        store_pair<ALIGNED>(prd, (size_t)r * ld + c0, outcol[0], outcol[1], pnew[0], pnew[1]);
+        store_pair<ALIGNED>(prd, (ptrdiff_t)r * ld + c0, outcol[0], outcol[1], pnew[0], pnew[1]);
         store_dp(r, dnew);
       }
     }
@@ -517,7 +572,9 @@ struct Task {
   __device__ __forceinline__ bool steady(int j) const {
     // passes 1..K work on rows j-1 .. j-K; the row requested ahead must exist
     return j - K > jstart && j + (DMA ? 0 : PF) <= jend && (DMA || j - K >= r0) &&
-           (!A.phys_bottom || j - K >= 2) && (!A.phys_top || j <= A.ny - 2);
+           (PAIR ? j <= jtop : ((!A.phys_bottom || j - K >= 2) && (!A.phys_top || j <= A.ny - 2)));
+    // (a task of a pair never starts at the window's bottom; without pairs pb, pt, nyt are A's own values --
+    //  written out here because the compiler then keeps 26 registers fewer)
   }
 
   // ---- register-path driver ----------------------------------------------------------------
@@ -601,11 +658,13 @@ struct Task {
           dma_step<0, false, QD>(j, sp, sg, drained);
           if (j + 1 <= jlast) dma_step<1, false, QD>(j + 1, sp, sg, drained);
         }
-        if (QD != DIV_IEEE && left_safe_window()) {
+        // (a pair runs to the end whatever happens: its two wavefronts meet at barriers)
+        if (!PAIR && QD != DIV_IEEE && left_safe_window()) {
           vm_wait<0>();  // rows still on their way into the rings must not land in the next run
           return false;
         }
       }
+      if (PAIR) return !(QD != DIV_IEEE && left_safe_window());
     } else {
 #pragma unroll
       for (int i = 0; i < PF; i++)
@@ -622,8 +681,11 @@ struct Task {
     return true;
   }
 
-  __device__ __forceinline__ void run_task() {
+  // Returns false when the task has to be produced again with IEEE division and cannot do that itself: the
+  // task of a pair, whose partner may be long gone -- the caller runs it again as a plain task.
+  __device__ __forceinline__ bool run_task() {
     const bool ok = run<DIV>();
+    if (PAIR) return ok;
 #ifdef NSK_POISSON_TRACE
     if (lane == 0) {
       atomicAdd(&nsk_trace_cnt[0], 1ull);
@@ -634,6 +696,7 @@ struct Task {
       reset();
       run<DIV_IEEE>();
     }
+    return true;
   }
 };
 
@@ -730,6 +793,65 @@ __global__ void __launch_bounds__(64) NSK_WAVES_ATTR k_poisson(PoissonArgs A) {
     nsk_trace_buf[blockIdx.x * 4 + 1] = wall_clock64();
     nsk_trace_buf[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
     nsk_trace_buf[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+#endif
+}
+
+// The same tasks, two per workgroup (a wavefront each), so that two of them can be a PAIR (see Task): the
+// chunks of a column strip are, from the bottom, one plain chunk, then pairs of a chunk that walks down and the
+// chunk above it that walks up, and a plain chunk on top when one is left over.  Every task then has halo rows
+// at one end only (the plain ones because their other end is the window's).  The host lists the tasks
+// (launch_pairs): entry 2*workgroup + wavefront.
+struct PairTask {
+  int sx, r0, r1, kind;  // kind: 0 = none, 1 = plain, 2 = walks down from r1-1 (partner: the other wavefront), 3 = walks up from r0
+};
+
+template <int K, int DIV, bool STREAM>
+__global__ void __launch_bounds__(128) NSK_WAVES_ATTR k_poisson_pairs(PoissonArgs A, const PairTask *__restrict__ table) {
+  constexpr int LDS_VEC = DmaGeometry<K>::LDS_BYTES / 16;
+  __shared__ double2 shared[2 * LDS_VEC + 4096 / 16];  // the two wavefronts' staging rings, the exchange slots
+#ifdef NSK_POISSON_TRACE
+  const unsigned long long trace_t0 = wall_clock64();
+#endif
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const PairTask *e = table + (2 * blockIdx.x + wave);
+  const int kind = __builtin_amdgcn_readfirstlane(e->kind), sx = __builtin_amdgcn_readfirstlane(e->sx);
+  const int r0 = __builtin_amdgcn_readfirstlane(e->r0), r1 = __builtin_amdgcn_readfirstlane(e->r1);
+  if (kind == 0) return;
+  double2 *rings = shared + wave * LDS_VEC;
+  constexpr int HK = (K + 1) & ~1;
+  constexpr int WOUT = 128 - 2 * HK;
+  const int cfirst = sx * WOUT - HK, clast = cfirst + 127;
+  if (kind >= 2) {  // (pairs are made of interior strips only)
+    const unsigned xch = (unsigned)(uintptr_t)(lds_void_t *)(shared + 2 * LDS_VEC);
+    bool ok;
+    {
+      Task<K, true, DIV, false, STREAM, true> t(A, rings, sx, r0, r1, kind == 2 ? r1 - 1 : -1, xch, wave);
+      ok = t.run_task();
+    }
+    if (DIV != DIV_IEEE && !ok) {
+      // A pressure value left the range of the fast division: the task is produced again with IEEE division, as
+      // a plain task with halo rows at both ends, from the launch's inputs -- nothing is needed from the
+      // partner, which decides for itself.
+      Task<K, true, DIV_IEEE, false, STREAM> again(A, rings, sx, r0, r1);
+      again.run_task();
+    }
+  } else if (cfirst < 1 || clast > A.nx - 2) {
+    Task<K, true, DIV, true, STREAM> t(A, rings, sx, r0, r1);
+    t.run_task();
+  } else {
+    Task<K, true, DIV, false, STREAM> t(A, rings, sx, r0, r1);
+    t.run_task();
+  }
+#ifdef NSK_POISSON_TRACE
+  const unsigned slot = 2 * blockIdx.x + wave;
+  if ((threadIdx.x & 63) == 0 && slot < NSK_POISSON_TRACE) {
+    nsk_trace_buf[slot * 4 + 0] = trace_t0;
+    nsk_trace_buf[slot * 4 + 1] = wall_clock64();
+    // (hardware ids in the low halves; the task in the high halves: kind, strip / first row)
+    nsk_trace_buf[slot * 4 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)kind << 32) |
+                                  ((unsigned long long)sx << 40);
+    nsk_trace_buf[slot * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((unsigned long long)r0 << 32);
   }
 #endif
 }
@@ -856,6 +978,79 @@ inline bool stream_inputs(int nx, int ny) {
 }
 
 // `plan` cuts the rows [A.row_begin, A.row_end) (plan_tasks was given their number).
+// One launch of k_poisson_pairs: the task list (cached per shape of the launch on the context), two tasks per
+// workgroup.  XCD-aware like k_poisson: workgroup i runs on XCD i % 8, and XCD x is given a contiguous band
+// of rows over all strips.
+template <int K>
+int launch_pairs(nsk_ctx *ctx, hipStream_t stream, const PoissonArgs &A, int div, const TaskPlan &plan, bool hint) {
+  const std::array<int, 8> key = {K, plan.nstrips, A.row_begin, A.row_end, plan.rows, plan.rows_edge, ctx->poisson_xcd, ctx->poisson_pairs};
+  auto it = ctx->pair_tables.find(key);
+  if (it == ctx->pair_tables.end()) {
+    if (ctx->pair_tables.size() >= 64) {  // (never in practice: a few shapes per grid)
+      NSK_HIP(hipStreamSynchronize(stream));
+      for (auto &kv : ctx->pair_tables) (void)hipFree(kv.second.first);
+      ctx->pair_tables.clear();
+    }
+    struct Group {
+      PairTask t[2];
+    };
+    std::vector<Group> groups;
+    std::vector<PairTask> plain;
+    auto cut = [&](int rows, std::vector<std::pair<int, int>> &out) {
+      out.clear();
+      for (int r = A.row_begin; r < A.row_end; r += rows) out.push_back({r, r + rows < A.row_end ? r + rows : A.row_end});
+    };
+    std::vector<std::pair<int, int>> ch;
+    cut(plan.rows, ch);
+    const int n = (int)ch.size();
+    constexpr int HK = (K + 1) & ~1, WOUT = 128 - 2 * HK;
+    for (int sx = 1; sx + 1 < plan.nstrips; sx++) {
+      // (a strip whose 128 columns reach the rim columns does the boundary-column work: no pairs there)
+      const bool rim = sx * WOUT - HK < 1 || sx * WOUT - HK + 127 > A.nx - 2;
+      plain.push_back(PairTask{sx, ch[0].first, ch[0].second, 1});
+      for (int c = 1; c < n;) {
+        if (ctx->poisson_pairs == 1 && !rim && c + 1 < n && ch[c + 1].second - ch[c + 1].first >= 2) {  // (2: the same launch, no pairs: for timing)
+          groups.push_back(Group{{PairTask{sx, ch[c].first, ch[c].second, 2}, PairTask{sx, ch[c + 1].first, ch[c + 1].second, 3}}});
+          c += 2;
+        } else {
+          plain.push_back(PairTask{sx, ch[c].first, ch[c].second, 1});
+          c += 1;
+        }
+      }
+    }
+    cut(plan.rows_edge, ch);
+    for (int side = 0; side < (plan.nstrips >= 2 ? 2 : 1); side++)
+      for (auto &c : ch) plain.push_back(PairTask{side == 0 ? 0 : plan.nstrips - 1, c.first, c.second, 1});
+    // plain tasks two by two, neighbours in the grid together
+    std::sort(plain.begin(), plain.end(), [](const PairTask &a, const PairTask &b) { return a.r0 != b.r0 ? a.r0 < b.r0 : a.sx < b.sx; });
+    for (size_t i = 0; i < plain.size(); i += 2)
+      groups.push_back(Group{{plain[i], i + 1 < plain.size() ? plain[i + 1] : PairTask{0, 0, 0, 0}}});
+    std::stable_sort(groups.begin(), groups.end(), [](const Group &a, const Group &b) {
+      return a.t[0].r0 != b.t[0].r0 ? a.t[0].r0 < b.t[0].r0 : a.t[0].sx < b.t[0].sx;
+    });
+    const size_t ng = groups.size(), per_band = (ng + 7) / 8, nblocks = ctx->poisson_xcd ? 8 * per_band : ng;
+    std::vector<PairTask> table(2 * nblocks, PairTask{0, 0, 0, 0});
+    for (size_t b = 0; b < nblocks; b++) {
+      const size_t src = ctx->poisson_xcd ? (b & 7) * per_band + (b >> 3) : b;
+      if (src < ng && (!ctx->poisson_xcd || (b >> 3) < per_band)) {
+        table[2 * b] = groups[src].t[0];
+        table[2 * b + 1] = groups[src].t[1];
+      }
+    }
+    PairTask *dev = nullptr;
+    NSK_HIP(hipMalloc(&dev, table.size() * sizeof(PairTask)));
+    NSK_HIP(hipMemcpy(dev, table.data(), table.size() * sizeof(PairTask), hipMemcpyHostToDevice));
+    it = ctx->pair_tables.emplace(key, std::make_pair((void *)dev, (unsigned)nblocks)).first;
+  }
+  const PairTask *table = static_cast<const PairTask *>(it->second.first);
+  const unsigned blocks = it->second.second;
+  if (div == DIV_FMA2 && hint) k_poisson_pairs<K, DIV_FMA2, true><<<blocks, 128, 0, stream>>>(A, table);
+  else if (div == DIV_FMA2) k_poisson_pairs<K, DIV_FMA2, false><<<blocks, 128, 0, stream>>>(A, table);
+  else k_poisson_pairs<K, DIV_IEEE, false><<<blocks, 128, 0, stream>>>(A, table);
+  NSK_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int K>
 int launch_k(nsk_ctx *ctx, hipStream_t stream, PoissonArgs &A, bool aligned, int div, const TaskPlan &plan) {
   A.nstrips = plan.nstrips;
@@ -884,6 +1079,11 @@ int launch_k(nsk_ctx *ctx, hipStream_t stream, PoissonArgs &A, bool aligned, int
 #define NSK_LAUNCH(AL, DV) k_poisson<K, AL, DV><<<tasks, 64, 0, stream>>>(A)
   // the hint is built for the form every shipped grid takes; the other forms do without
   const bool hint = ctx->poisson_stream < 0 ? stream_inputs(A.nx, A.ny) : ctx->poisson_stream != 0;
+  // Tasks in pairs that share no halo rows: pitched storage, one row range, chunks tall enough for the K
+  // exchanges, and a caller that may allocate (the task list lives in device memory).
+  if (aligned && ctx->poisson_pairs && !ctx->no_alloc_call && (div == DIV_FMA2 || div == DIV_IEEE) && plan.nchunks1 < 0 &&
+      A.row2_end <= A.row2_begin && plan.nstrips >= 3 && plan.rows >= K + 2 && plan.rows_edge >= 2 && A.tall_extra == 0)
+    return launch_pairs<K>(ctx, stream, A, div, plan, hint);
   if (aligned && div == DIV_FMA2 && hint) {
     k_poisson<K, true, DIV_FMA2, true><<<tasks, 64, 0, stream>>>(A);
   } else if (aligned) {

@@ -52,6 +52,10 @@ extern "C" int nsk_create(int device, nsk_ctx **out) {
     const int v = atoi(k);
     if (v >= 0 && v <= 8) c->poisson_k = v;
   }
+  if (const char *q = getenv("NSK_POISSON_PAIRS")) {  // (A/B runs of programs that set no options)
+    const int v = atoi(q);
+    if (v >= 0 && v <= 2) c->poisson_pairs = v;
+  }
   if (const char *r = getenv("NSK_POISSON_ROWS")) {
     const int v = atoi(r);
     if (v >= 0) c->poisson_rows = v;
@@ -93,6 +97,7 @@ extern "C" int nsk_destroy(nsk_ctx *c) {
   if (c->sor_grid_ctl) (void)hipFree(c->sor_grid_ctl);
   if (c->run_words) (void)hipFree(c->run_words);
   if (c->small_xbuf) (void)hipFree(c->small_xbuf);
+  for (auto &kv : c->pair_tables) (void)hipFree(kv.second.first);
   if (c->ev_edge) (void)hipEventDestroy(c->ev_edge);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->hist_dev) (void)hipFree(c->hist_dev);
@@ -181,6 +186,11 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "poisson_small")) {
     NSK_REQUIRE(value == 0 || value == 1, "poisson_small must be 0 or 1, got %d", value);
     ctx->poisson_small = value;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_pairs")) {
+    NSK_REQUIRE(value >= 0 && value <= 2, "poisson_pairs must be 0, 1 or 2, got %d", value);
+    ctx->poisson_pairs = value;
     return 0;
   }
   if (!strcmp(name, "poisson_small_spin_limit") || !strcmp(name, "poisson_small_test_absent")) {
@@ -278,6 +288,10 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
   }
   if (!strcmp(name, "poisson_small")) {
     *value = ctx->poisson_small;
+    return 0;
+  }
+  if (!strcmp(name, "poisson_pairs")) {
+    *value = ctx->poisson_pairs;
     return 0;
   }
   if (!strcmp(name, "poisson_small_halo")) {

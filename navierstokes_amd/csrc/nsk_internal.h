@@ -6,6 +6,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <array>
+#include <map>
+#include <utility>
 
 #include "../../include/nsk.h"
 
@@ -41,6 +44,10 @@ struct nsk_ctx {
   int poisson_div = -1;  // -1 = automatic; 0 / 2 / 3 / 4 ask for a division form (testing)
   int last_div = -1;     // form the last fused Poisson call used (nsk_get_option "poisson_div_used")
   int poisson_edge_percent = 0;  // rows per task of the edge strips in % of poisson_rows, 0 = default
+  int poisson_pairs = 1;  // 1 = tasks of the multi-pass kernel in pairs that walk away from a common row (no halo rows between them)
+  bool no_alloc_call = false;  // inside nsk_ns_poisson_iters_static: nothing may be allocated
+  // task lists of those launches, by the shape of the launch: (device pointer, workgroups)
+  std::map<std::array<int, 8>, std::pair<void *, unsigned>> pair_tables;
   int poisson_tall_percent = 0;  // interior chunks in pairs of poisson_rows*(100 +- this)/100 rows, 0 = all alike
   int poisson_xcd = 1;   // XCD-aware task numbering of the Poisson kernel (0 = plain)
   int poisson_stream = -1;  // non-temporal requests for Pr and dPrdtau rows: -1 = by the size of the fields, 0 / 1

@@ -48,7 +48,10 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
     edge_stream = torch.cuda.Stream()
     interesting = [3, 4, 5, 6, 7, 113, 114, 115, 116, 117, 118, 119, 127, 128, 129, 130, 231, 232, 233, 234, 255, 256, 257]
     t_start, bad = time.time(), 0
+    only = int(os.environ.get("FUZZ_ONLY", "-1"))         # run this case alone (the others only draw their random numbers)
+    extra = [o.split("=") for o in os.environ.get("FUZZ_OPTS", "").split()]   # name=value options on top of the drawn ones
     for case in range(a.cases):
+        skip = only >= 0 and case != only
         def dim():
             if rng.random() < 0.4:
                 return int(rng.choice(interesting))
@@ -94,7 +97,7 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
                 hi = nyg
         Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
         with np.errstate(all="ignore"):
-            for _ in range(count):
+            for _ in range(0 if skip else count):
                 oracle.update_dPrdtau(Pr, dP, dv, p.rho, p.dt, p.dtau, p.damp, p.dx, p.dy)
                 oracle.update_Pr(Pr, dP, p.dtau)
                 oracle.set_bc_Pr(Pr, 0.0, bool(full))
@@ -105,6 +108,8 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
                        ("poisson_stream", stream), ("poisson_small", small), ("poisson_small_halo", s_halo),
                        ("poisson_small_cols", s_cols), ("poisson_small_rows", s_rows)):
             ctx.set_option(opt, v)
+        for name, v in extra:
+            ctx.set_option(name, int(v))
         if pitched:
             ld = _pitch(nx)
             dPr, dDv = Dev(wPr, ld, pad_value=np.nan), Dev(wdv, ld, pad_value=np.nan)
@@ -125,9 +130,13 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
             sk_hi, e_hi = (cut[0], cut[1] - cut[0]) if hi < nyg else (0, int(rng.integers(0, nyw // 2)))
             ef = (sk_lo, e_lo, e_hi, sk_hi)
             ctx.set_option("poisson_edge_task_rows", int(rng.choice([0, 0, 2, 3, 12])))
+            if skip:
+                continue
             ctx.ns_poisson_iters_edges_first(dPr.ptr, dDp.ptr, dDv.ptr, C.byref(cp), count, sk_lo, e_lo, e_hi, sk_hi,
                                              C.c_void_p(edge_stream.cuda_stream))
             edge_stream.synchronize()
+        elif skip:
+            continue
         else:
             ctx.ns_poisson_iters(dPr.ptr, dDp.ptr, dDv.ptr, C.byref(cp), count)
         gPr = dPr.get()

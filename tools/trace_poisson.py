@@ -18,6 +18,7 @@ ap.add_argument("--k", type=int, default=5)
 ap.add_argument("--rows", type=int, default=0)
 ap.add_argument("--edge", type=int, default=0)
 ap.add_argument("--tall", type=int, default=0, help="poisson_tall_percent")
+ap.add_argument("--pairs", type=int, default=1, help="poisson_pairs: tasks in pairs that walk away from a common row")
 a = ap.parse_args()
 p = ns_params("NavierStokes_Re6", n=16)
 nx, ny = p.nx, p.ny
@@ -37,6 +38,7 @@ ctx.set_option("poisson_k", a.k)
 ctx.set_option("poisson_rows", a.rows)
 ctx.set_option("poisson_edge_percent", a.edge)
 ctx.set_option("poisson_tall_percent", a.tall)
+ctx.set_option("poisson_pairs", a.pairs)
 ctx.ns_poisson_iters(ptr(Pr), ptr(dP), ptr(dv), C.byref(cp), a.k * 6)
 torch.cuda.synchronize()
 lib = _lib.load()
@@ -51,6 +53,8 @@ t0 = b[:, 0].astype(np.int64); t1 = b[:, 1].astype(np.int64)
 base = t0.min()
 st = (t0 - base) / 100.0; en = (t1 - base) / 100.0   # us
 dur = en - st
+kind = (b[:, 2] >> 32) & 0xFF; strip = (b[:, 2] >> 40) & 0xFFFF; first_row = b[:, 3] >> 32      # (filled in by the paired launch)
+b[:, 2] &= 0xFFFFFFFF; b[:, 3] &= 0xFFFFFFFF
 hw = b[:, 2]; xcc = b[:, 3] & 0xF
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
 print(f"tasks {len(b)}  span {en.max():.1f} us  start: max {st.max():.1f}  dur: mean {dur.mean():.1f} min {dur.min():.1f} max {dur.max():.1f} p50 {np.median(dur):.1f} p90 {np.percentile(dur,90):.1f}")
@@ -97,3 +101,13 @@ if first:
     print(f"SIMDs with two tasks: {len(first)}; smaller number: duration mean {dur[first].mean():.1f}, end mean {en[first].mean():.1f}; "
           f"larger number: duration mean {dur[second].mean():.1f}, end mean {en[second].mean():.1f}; "
           f"pairs whose smaller number is in the first half and larger in the second: {int(((idx[first] < half) & (idx[second] >= half)).sum())}")
+
+if kind.any():
+    nstrips = int(strip.max()) + 1
+    for name, m in (("plain, interior strips", (kind == 1) & (strip > 0) & (strip < nstrips - 1)), ("plain, edge strips", (kind == 1) & ((strip == 0) | (strip == nstrips - 1))),
+                    ("pair, walks down", kind == 2), ("pair, walks up", kind == 3)):
+        if m.any():
+            print(f"{name}: {m.sum()} tasks, duration mean {dur[m].mean():.1f} p10 {np.percentile(dur[m],10):.1f} p90 {np.percentile(dur[m],90):.1f} max {dur[m].max():.1f}, "
+                  f"end mean {en[m].mean():.1f} max {en[m].max():.1f}")
+    slow = order[-12:]
+    print("slowest 12 (kind, strip, first row, duration):", [(int(kind[i]), int(strip[i]), int(first_row[i]), round(float(dur[i]), 1)) for i in slow])
