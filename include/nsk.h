@@ -100,8 +100,10 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *   "poisson_pairs"        launches of "poisson_k" passes on pitched storage: 1 = the tasks of a column strip in
  *                          pairs that start at a common row and walk away from it, one up and one down the
  *                          array, handing each other that row's values of every pass through LDS, so that
- *                          neither recomputes halo rows at that end (default; 5-7 % faster at 2559 x 4095),
- *                          0 = every task with halo rows at both ends, 2 = the launch shape of 1 without
+ *                          neither recomputes halo rows at that end -- where the launch planner estimates
+ *                          that form to be the faster one (default; 5-7 % faster at 2559 x 4095),
+ *                          3 = in pairs wherever the launch can have them (for tests),
+ *                          0 = every task with halo rows at both ends, 2 = the launch shape of 3 without
  *                          pairs (for timing).  NSK_POISSON_PAIRS in the environment sets the default.
  *   "poisson_tall_percent" launches of "poisson_k" passes: interior tasks in pairs of
  *                          poisson_rows * (100 +- this) / 100 rows that start together, so that the last

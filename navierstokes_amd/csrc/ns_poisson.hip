@@ -351,12 +351,13 @@ int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double 
 
   // Passes per launch and task shape: forced by the options, otherwise the cheapest by the
   // planner's estimate for this grid.
-  // (with the interior tasks in pairs -- halo rows at one end only -- the tasks of the two rim strips, which
-  //  keep theirs at both ends, are cut shorter still: 62 % of the interior height instead of 75)
-  const bool pairs_likely = aligned && ctx->poisson_pairs && !ctx->no_alloc_call && !ef && (div == DIV_FMA2 || div == DIV_IEEE);
-  const int ep = ctx->poisson_edge_percent > 0 ? ctx->poisson_edge_percent : (pairs_likely ? 62 : 0);
+  // (tasks in pairs: pitched storage, whole-window launches, a caller that may allocate; the planner weighs
+  //  them against plain tasks unless the option says "wherever they fit")
+  const int pairs_likely = aligned && ctx->poisson_pairs && !ctx->no_alloc_call && !ef && (div == DIV_FMA2 || div == DIV_IEEE)
+                               ? (ctx->poisson_pairs == 1 ? 1 : 2) : 0;
+  const int ep = ctx->poisson_edge_percent;
   const TaskPlan top = choose_plan(nx, ny, ctx->num_simds, aligned, ctx->poisson_k, count < 8 ? count : 8,
-                                   ctx->poisson_rows, ep);
+                                   ctx->poisson_rows, ep, pairs_likely);
   const int kmax = top.K;
   ctx->last_plan_k = top.K;
   ctx->last_plan_rows = top.rows;
@@ -403,7 +404,7 @@ int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double 
       A.row_end = ny;
       edges_cut = true;
     } else {
-      const TaskPlan plan = k == top.K ? top : choose_plan(nx, ny, ctx->num_simds, aligned, k, k, ctx->poisson_rows, ep);
+      const TaskPlan plan = k == top.K ? top : choose_plan(nx, ny, ctx->num_simds, aligned, k, k, ctx->poisson_rows, ep, pairs_likely);
       if (int rc = launch_poisson(ctx, ctx->stream, A, aligned, div, plan)) return rc;
     }
     left -= k;

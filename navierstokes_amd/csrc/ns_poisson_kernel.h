@@ -875,16 +875,26 @@ struct TaskPlan {
   long tasks;
   double est_us_per_pass;
   int nchunks1 = -1, nchunks1_edge = -1;  // chunks that belong to the first of two row ranges (-1: all)
+  bool pairs = false;     // the tasks of the interior strips in pairs (k_poisson_pairs, two tasks per workgroup)
+  long slots = 0;         // wavefront slots the launch takes: the tasks, or two per workgroup
 };
 
-inline TaskPlan plan_tasks(int K, int nx, int ny, int rows, int edge_percent) {
+// Can a launch of K passes with this plan run its tasks in pairs?  (The two wavefronts of a workgroup and the
+// exchange slots must fit a quarter of a compute unit's LDS; a chunk must outlast the K exchanges.)
+inline bool pairs_fit(int K, int nstrips, int rows, int rows_edge) {
+  return 2 * DmaGeometry<1>::LDS_BYTES + 2 * 1024 * (K - 1) + 4096 <= 40960 && nstrips >= 3 && rows >= K + 2 && rows_edge >= 2;
+}
+
+inline TaskPlan plan_tasks(int K, int nx, int ny, int rows, int edge_percent, bool pairs = false) {
   TaskPlan t;
   const int HK = (K + 1) & ~1, WOUT = 128 - 2 * HK;
   t.K = K;
   t.nstrips = (nx - 1 + WOUT - 1) / WOUT;  // columns 0..nx-2; nx-1 rides with nx-2
   if (rows < 2) rows = 2;
   if (rows > ny) rows = ny;
-  int re = (int)((long)rows * (edge_percent > 0 ? edge_percent : 75) / 100);
+  // (with the interior tasks in pairs -- halo rows at one end only -- the tasks that do the boundary-column work,
+  //  which keep theirs at both ends, are cut shorter still)
+  int re = (int)((long)rows * (edge_percent > 0 ? edge_percent : (pairs ? 62 : 75)) / 100);
   if (re < 2) re = 2;
   if (re > rows) re = rows;
   t.rows = rows;
@@ -894,6 +904,26 @@ inline TaskPlan plan_tasks(int K, int nx, int ny, int rows, int edge_percent) {
   const int nint = t.nstrips > 2 ? t.nstrips - 2 : 0, nedge = t.nstrips >= 2 ? 2 : 1;
   t.tasks = (long)nint * t.nchunks + (long)nedge * t.nchunks_edge;
   t.est_us_per_pass = 0.0;
+  t.slots = t.tasks;
+  if (pairs && pairs_fit(K, t.nstrips, rows, re)) {
+    // as launch_pairs lists them: per strip one plain chunk, then pairs, a plain one when a chunk is left over;
+    // strips that reach the rim columns plain throughout; plain tasks two per workgroup
+    long npairs = 0, plain = (long)nedge * t.nchunks_edge;
+    const int n = t.nchunks, last_rows = ny - (n - 1) * rows;
+    for (int sx = 1; sx + 1 < t.nstrips; sx++) {
+      const bool rim = sx * WOUT - HK < 1 || sx * WOUT - HK + 127 > nx - 2;
+      if (rim) {  // (cut like the first and the last strip: the boundary-column work rides on its tasks too)
+        plain += t.nchunks_edge;
+        continue;
+      }
+      int m = n - 1, p = m / 2, left = m % 2;
+      if (p > 0 && left == 0 && last_rows < 2) p -= 1, left = 2;  // (a last chunk of one row is no partner)
+      npairs += p;
+      plain += 1 + left;
+    }
+    t.pairs = true;
+    t.slots = 2 * (npairs + (plain + 1) / 2);
+  }
   return t;
 }
 
@@ -921,19 +951,23 @@ inline TaskPlan plan_two_ranges(int K, int nx, int n1, int n2, int rows, int edg
 inline double plan_cost(const TaskPlan &t, int nx, int ny, int num_simds) {
   const int K = t.K, HK = (K + 1) & ~1, WOUT = 128 - 2 * HK;
   const long slots = (long)num_simds * NSK_WAVES;
-  const double rounds = (double)((t.tasks + slots - 1) / slots);
-  const double per_step = t.tasks > num_simds ? 0.30 + 0.23 * K : 0.18 + 0.14 * K;
-  const double alu = rounds * (t.rows + 2 * K) * per_step;
+  const double rounds = (double)((t.slots + slots - 1) / slots);
+  // (the two wavefronts of a workgroup of a paired launch are placed without regard to the wavefronts a SIMD
+  //  already holds: only with no more workgroups than compute units does every wavefront have a SIMD to itself)
+  const bool shared_simds = t.pairs ? t.slots > num_simds / 2 : t.tasks > num_simds;
+  const double per_step = shared_simds ? 0.30 + 0.23 * K : 0.18 + 0.14 * K;
+  const int halo_steps = t.pairs ? K + 1 : 2 * K;  // (a task of a pair has halo rows at one end only)
+  const double alu = rounds * (t.rows + halo_steps) * per_step;
   const double field_bytes = 8.0 * nx * ny;
   const double rate = 5.0 * field_bytes < 200e6 ? 10.4e6 : 5.2e6;  // bytes per us
-  const double mem = field_bytes * (3.0 * (1.0 + 2.0 * K / t.rows) * (128.0 / WOUT) + 2.0) / rate;
+  const double mem = field_bytes * (3.0 * (1.0 + (double)halo_steps / t.rows) * (128.0 / WOUT) + 2.0) / rate;
   return ((alu > mem ? alu : mem) + 5.0) / K;
 }
 
 // Passes per launch and chunk height.  k_forced / rows_forced > 0 pin the respective choice;
 // k_limit caps the automatic K (no more passes than are asked for).
 inline TaskPlan choose_plan(int nx, int ny, int num_simds, bool staged, int k_forced, int k_limit,
-                            int rows_forced, int edge_percent) {
+                            int rows_forced, int edge_percent, int pairs = 0) {
   // automatic K stops where the kernel no longer fits two wavefronts per SIMD: 6 passes with the
   // LDS-staged input path, 5 when the input rows travel through registers
   int klo = 1, khi = staged ? 6 : 5;
@@ -943,25 +977,30 @@ inline TaskPlan choose_plan(int nx, int ny, int num_simds, bool staged, int k_fo
   const long slots = (long)num_simds * NSK_WAVES;
   TaskPlan best{};
   bool have = false;
-  for (int K = klo; K <= khi; K++) {
-    int rlo = rows_forced, rhi = rows_forced;
-    if (rows_forced <= 0) {
-      // from the smallest height that fits one round to the one that leaves one task per SIMD
-      rlo = 2;
-      while (rlo < ny && plan_tasks(K, nx, ny, rlo, edge_percent).tasks > slots) rlo++;
-      rhi = rlo;
-      while (rhi < ny && plan_tasks(K, nx, ny, rhi, edge_percent).tasks > num_simds) rhi++;
-      if (rhi > rlo + 256) rhi = rlo + 256;
-    }
-    for (int r = rlo; r <= rhi; r++) {
-      TaskPlan t = plan_tasks(K, nx, ny, r, edge_percent);
-      t.est_us_per_pass = plan_cost(t, nx, ny, num_simds);
-      if (!have || t.est_us_per_pass < best.est_us_per_pass) {
-        best = t;
-        have = true;
+  for (int K = klo; K <= khi; K++)
+    for (int form = pairs == 2 ? 1 : 0; form <= (pairs ? 1 : 0); form++) {  // plain tasks; tasks in pairs where the launch can have them
+                                                                               // (pairs: 0 never, 1 the cheaper form by the estimate, 2 wherever they fit)
+      const bool pr = form == 1;
+      const long alone = pr ? num_simds / 2 : num_simds;
+      int rlo = rows_forced, rhi = rows_forced;
+      if (rows_forced <= 0) {
+        // from the smallest height that fits one round to the one that leaves every wavefront a SIMD to itself
+        rlo = 2;
+        while (rlo < ny && plan_tasks(K, nx, ny, rlo, edge_percent, pr).slots > slots) rlo++;
+        rhi = rlo;
+        while (rhi < ny && plan_tasks(K, nx, ny, rhi, edge_percent, pr).slots > alone) rhi++;
+        if (rhi > rlo + 256) rhi = rlo + 256;
+      }
+      for (int r = rlo; r <= rhi; r++) {
+        TaskPlan t = plan_tasks(K, nx, ny, r, edge_percent, pr);
+        if (pr && !t.pairs && pairs != 2) continue;  // (this height cannot be paired: the plain form has it already)
+        t.est_us_per_pass = plan_cost(t, nx, ny, num_simds);
+        if (!have || t.est_us_per_pass < best.est_us_per_pass) {
+          best = t;
+          have = true;
+        }
       }
     }
-  }
   return best;
 }
 
@@ -1000,16 +1039,21 @@ int launch_pairs(nsk_ctx *ctx, hipStream_t stream, const PoissonArgs &A, int div
       out.clear();
       for (int r = A.row_begin; r < A.row_end; r += rows) out.push_back({r, r + rows < A.row_end ? r + rows : A.row_end});
     };
-    std::vector<std::pair<int, int>> ch;
+    std::vector<std::pair<int, int>> ch, che;
     cut(plan.rows, ch);
+    cut(plan.rows_edge, che);
     const int n = (int)ch.size();
     constexpr int HK = (K + 1) & ~1, WOUT = 128 - 2 * HK;
     for (int sx = 1; sx + 1 < plan.nstrips; sx++) {
-      // (a strip whose 128 columns reach the rim columns does the boundary-column work: no pairs there)
-      const bool rim = sx * WOUT - HK < 1 || sx * WOUT - HK + 127 > A.nx - 2;
+      // (a strip whose 128 columns reach the rim columns does the boundary-column work: no pairs there, and
+      //  chunks as short as those of the first and the last strip)
+      if (sx * WOUT - HK < 1 || sx * WOUT - HK + 127 > A.nx - 2) {
+        for (auto &c : che) plain.push_back(PairTask{sx, c.first, c.second, 1});
+        continue;
+      }
       plain.push_back(PairTask{sx, ch[0].first, ch[0].second, 1});
       for (int c = 1; c < n;) {
-        if (ctx->poisson_pairs == 1 && !rim && c + 1 < n && ch[c + 1].second - ch[c + 1].first >= 2) {  // (2: the same launch, no pairs: for timing)
+        if (ctx->poisson_pairs != 2 && c + 1 < n && ch[c + 1].second - ch[c + 1].first >= 2) {  // (2: the same launch, no pairs: for timing)
           groups.push_back(Group{{PairTask{sx, ch[c].first, ch[c].second, 2}, PairTask{sx, ch[c + 1].first, ch[c + 1].second, 3}}});
           c += 2;
         } else {
@@ -1018,9 +1062,8 @@ int launch_pairs(nsk_ctx *ctx, hipStream_t stream, const PoissonArgs &A, int div
         }
       }
     }
-    cut(plan.rows_edge, ch);
     for (int side = 0; side < (plan.nstrips >= 2 ? 2 : 1); side++)
-      for (auto &c : ch) plain.push_back(PairTask{side == 0 ? 0 : plan.nstrips - 1, c.first, c.second, 1});
+      for (auto &c : che) plain.push_back(PairTask{side == 0 ? 0 : plan.nstrips - 1, c.first, c.second, 1});
     // plain tasks two by two, neighbours in the grid together
     std::sort(plain.begin(), plain.end(), [](const PairTask &a, const PairTask &b) { return a.r0 != b.r0 ? a.r0 < b.r0 : a.sx < b.sx; });
     for (size_t i = 0; i < plain.size(); i += 2)
@@ -1082,7 +1125,7 @@ int launch_k(nsk_ctx *ctx, hipStream_t stream, PoissonArgs &A, bool aligned, int
   // Tasks in pairs that share no halo rows: pitched storage, one row range, chunks tall enough for the K
   // exchanges, and a caller that may allocate (the task list lives in device memory).
   if (aligned && ctx->poisson_pairs && !ctx->no_alloc_call && (div == DIV_FMA2 || div == DIV_IEEE) && plan.nchunks1 < 0 &&
-      A.row2_end <= A.row2_begin && plan.nstrips >= 3 && plan.rows >= K + 2 && plan.rows_edge >= 2 && A.tall_extra == 0)
+      A.row2_end <= A.row2_begin && plan.pairs && pairs_fit(K, plan.nstrips, plan.rows, plan.rows_edge) && A.tall_extra == 0)
     return launch_pairs<K>(ctx, stream, A, div, plan, hint);
   if (aligned && div == DIV_FMA2 && hint) {
     k_poisson<K, true, DIV_FMA2, true><<<tasks, 64, 0, stream>>>(A);

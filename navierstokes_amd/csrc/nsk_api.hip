@@ -54,7 +54,7 @@ extern "C" int nsk_create(int device, nsk_ctx **out) {
   }
   if (const char *q = getenv("NSK_POISSON_PAIRS")) {  // (A/B runs of programs that set no options)
     const int v = atoi(q);
-    if (v >= 0 && v <= 2) c->poisson_pairs = v;
+    if (v >= 0 && v <= 3) c->poisson_pairs = v;
   }
   if (const char *r = getenv("NSK_POISSON_ROWS")) {
     const int v = atoi(r);
@@ -189,7 +189,7 @@ extern "C" int nsk_set_option(nsk_ctx *ctx, const char *name, int value) {
     return 0;
   }
   if (!strcmp(name, "poisson_pairs")) {
-    NSK_REQUIRE(value >= 0 && value <= 2, "poisson_pairs must be 0, 1 or 2, got %d", value);
+    NSK_REQUIRE(value >= 0 && value <= 3, "poisson_pairs must be 0 .. 3, got %d", value);
     ctx->poisson_pairs = value;
     return 0;
   }

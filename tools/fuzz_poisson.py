@@ -44,6 +44,7 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
     """Runs the cases on context `ctx`; returns the descriptions of the mismatching ones."""
     a = argparse.Namespace(cases=cases, seed=seed, max_n=max_n)
     rng = np.random.default_rng(a.seed)
+    rng_pairs = np.random.default_rng(a.seed + 7919)      # (its own stream: the cases of a seed stay what they were)
     failures = []
     edge_stream = torch.cuda.Stream()
     interesting = [3, 4, 5, 6, 7, 113, 114, 115, 116, 117, 118, 119, 127, 128, 129, 130, 231, 232, 233, 234, 255, 256, 257]
@@ -66,6 +67,7 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
         xcd = int(rng.integers(0, 2))
         stream = int(rng.integers(-1, 2))
         full = int(rng.integers(0, 2))
+        pairs = int(rng_pairs.choice([0, 1, 3, 3]))       # tasks in pairs: never, where estimated faster, wherever they fit
         count = int(rng.integers(1, 3 * max(K, 3) + 2))
         # whole runs of passes in one launch (grids whose tiles fit on chip): on or off, frame width, tile shape
         small = int(rng.integers(0, 2))
@@ -105,7 +107,7 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
         wdP = np.asfortranarray(dP0[:, lo:hi - 2])
         nyw = hi - lo
         for opt, v in (("poisson_k", K), ("poisson_rows", rows), ("poisson_edge_percent", edge), ("poisson_xcd", xcd),
-                       ("poisson_stream", stream), ("poisson_small", small), ("poisson_small_halo", s_halo),
+                       ("poisson_stream", stream), ("poisson_pairs", pairs), ("poisson_small", small), ("poisson_small_halo", s_halo),
                        ("poisson_small_cols", s_cols), ("poisson_small_rows", s_rows)):
             ctx.set_option(opt, v)
         for name, v in extra:
@@ -156,7 +158,7 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
         if hi < nyg and sk_hi == 0:
             ok = ok and strict_same(gPr[:, -1], wPr[:, -1])
         desc = (f"case {case}: nx={nx} nyg={nyg} window=[{lo},{hi}) pitched={pitched} K={K}->{ctx.get_option('poisson_k')} rows={rows} "
-                f"edge={edge} xcd={xcd} stream={stream} full={full} count={count} scale={scale} zeros={zero_frac} div={ctx.get_option('poisson_div_used')} "
+                f"edge={edge} xcd={xcd} stream={stream} pairs={pairs} full={full} count={count} scale={scale} zeros={zero_frac} div={ctx.get_option('poisson_div_used')} "
                 f"edges_first={ef} one_launch={small} frame={s_halo} tile={s_cols}x{s_rows}")
         if not ok:
             bad += 1
@@ -168,6 +170,7 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
                 "poisson_small_cols", "poisson_small_rows"):
         ctx.set_option(opt, 0)
     ctx.set_option("poisson_small", 1)
+    ctx.set_option("poisson_pairs", 1)
     ctx.set_option("poisson_xcd", 1)
     ctx.set_option("poisson_stream", -1)
     if verbose:

@@ -19,8 +19,9 @@ ap.add_argument("--rows", type=int, default=0)
 ap.add_argument("--edge", type=int, default=0)
 ap.add_argument("--tall", type=int, default=0, help="poisson_tall_percent")
 ap.add_argument("--pairs", type=int, default=1, help="poisson_pairs: tasks in pairs that walk away from a common row")
+ap.add_argument("--n", type=int, default=16, help="grid: nx = 160 n - 1, ny = 256 n - 1")
 a = ap.parse_args()
-p = ns_params("NavierStokes_Re6", n=16)
+p = ns_params("NavierStokes_Re6", n=a.n)
 nx, ny = p.nx, p.ny
 ld = _pitch(nx)
 torch.cuda.set_device(0)
