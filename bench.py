@@ -296,7 +296,8 @@ def main():
     alg_bytes = 40.0 * nx * slab.ny_win * kpl
     achieved = alg_bytes / t_launch / 1e9
 
-    kernel = f"k_poisson<{kpl}>"
+    paired = group is None and ctx.get_option("poisson_pairs_used") == 1   # (the launch's tasks in pairs: its own kernel)
+    kernel = f"k_poisson_pairs<{kpl}>" if paired else f"k_poisson<{kpl}>"
     cnt = poisson_counters(kernel, nx, slab.ny_win)
     traffic = fabric_frac = valu_frac = valu_sus = clock_sus = None
     if cnt:

@@ -317,11 +317,18 @@ struct Task {
   // ∇V, which every launch reads again, without).  Values do not depend on it; when it pays is the
   // host's decision (stream_inputs).
   __device__ __forceinline__ void dma_row(int j, int sp, int sg) {
-    constexpr int AUX = STREAM ? 2 : 0;
     const ptrdiff_t off = (ptrdiff_t)j * ld + (ptrdiff_t)cc;
     char *base = reinterpret_cast<char *>(lds);
-    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(prs + off), (lds_void_t *)(base + sp * 1024), 16, 0, AUX);
-    __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(dps + off), (lds_void_t *)(base + (NST + sp) * 1024), 16, 0, AUX);
+    // (the rows around the far end are read by the task beyond it as well, at about the same time -- its halo
+    //  rows and ours: those without the hint, so that the second reader finds them in L2: 7 % fewer bytes
+    //  from the fabric at 2559 x 4095, the same time)
+    if (STREAM && j < r1 - 2 * K) {
+      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(prs + off), (lds_void_t *)(base + sp * 1024), 16, 0, 2);
+      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(dps + off), (lds_void_t *)(base + (NST + sp) * 1024), 16, 0, 2);
+    } else {
+      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(prs + off), (lds_void_t *)(base + sp * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(dps + off), (lds_void_t *)(base + (NST + sp) * 1024), 16, 0, 0);
+    }
     __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(dvs + off), (lds_void_t *)(base + (2 * NST + sg) * 1024), 16, 0, 0);
   }
 
@@ -650,7 +657,14 @@ struct Task {
         if (jstart + i <= jend) dma_row(jstart + i, i % NST, i % NSG);
       int sp = 0, sg = 0;
       bool drained = false;
+      // Two wavefronts share a SIMD, and the arbiter serves the older one first: it ran at nearly the speed it
+      // would have alone and the younger one finished a quarter later, alone on the SIMD.  They take turns at
+      // the higher priority instead, two row steps each (the parity of the hardware wavefront slot tells the
+      // two apart; should both slots of a SIMD have the same parity nothing changes): 1.5-2 % per launch.
+      const int slot_parity = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 1u);  // HW_ID, wave_id bit 0
       for (int j = jstart; j <= jlast; j += 2) {
+        if ((((j - jstart) >> 1) & 1) == slot_parity) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
         if (steady(j) && steady(j + 1)) {
           dma_step<0, true, QD>(j, sp, sg, drained);
           dma_step<1, true, QD>(j + 1, sp, sg, drained);
@@ -1125,8 +1139,11 @@ int launch_k(nsk_ctx *ctx, hipStream_t stream, PoissonArgs &A, bool aligned, int
   // Tasks in pairs that share no halo rows: pitched storage, one row range, chunks tall enough for the K
   // exchanges, and a caller that may allocate (the task list lives in device memory).
   if (aligned && ctx->poisson_pairs && !ctx->no_alloc_call && (div == DIV_FMA2 || div == DIV_IEEE) && plan.nchunks1 < 0 &&
-      A.row2_end <= A.row2_begin && plan.pairs && pairs_fit(K, plan.nstrips, plan.rows, plan.rows_edge) && A.tall_extra == 0)
+      A.row2_end <= A.row2_begin && plan.pairs && pairs_fit(K, plan.nstrips, plan.rows, plan.rows_edge) && A.tall_extra == 0) {
+    ctx->last_launch_pairs = 1;
     return launch_pairs<K>(ctx, stream, A, div, plan, hint);
+  }
+  ctx->last_launch_pairs = 0;
   if (aligned && div == DIV_FMA2 && hint) {
     k_poisson<K, true, DIV_FMA2, true><<<tasks, 64, 0, stream>>>(A);
   } else if (aligned) {

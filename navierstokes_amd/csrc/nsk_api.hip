@@ -290,6 +290,10 @@ extern "C" int nsk_get_option(nsk_ctx *ctx, const char *name, int *value) {
     *value = ctx->poisson_small;
     return 0;
   }
+  if (!strcmp(name, "poisson_pairs_used")) {
+    *value = ctx->last_launch_pairs;
+    return 0;
+  }
   if (!strcmp(name, "poisson_pairs")) {
     *value = ctx->poisson_pairs;
     return 0;

@@ -41,6 +41,7 @@ struct nsk_ctx {
   size_t iter_pp_elems = 0;
   int poisson_k = 0;     // passes per launch, 0 = chosen per grid (NSK_POISSON_K / nsk_set_option)
   int last_plan_k = 0, last_plan_rows = 0;  // what the last fused Poisson call used (nsk_get_option)
+  int last_launch_pairs = 0;                // its last launch ran its tasks in pairs (k_poisson_pairs)
   int poisson_div = -1;  // -1 = automatic; 0 / 2 / 3 / 4 ask for a division form (testing)
   int last_div = -1;     // form the last fused Poisson call used (nsk_get_option "poisson_div_used")
   int poisson_edge_percent = 0;  // rows per task of the edge strips in % of poisson_rows, 0 = default

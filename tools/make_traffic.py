@@ -20,24 +20,32 @@ from navierstokes_amd._lib import poisson_kernel_hash
 ap = argparse.ArgumentParser()
 ap.add_argument("--k", type=int, required=True)
 ap.add_argument("--grid", type=int, nargs=2, required=True)
-ap.add_argument("--round", type=int, default=2)
+ap.add_argument("--round", type=int, default=3)
 ap.add_argument("dbs", nargs="+")
 a = ap.parse_args()
 
-vals = {}
-for path in a.dbs:
-    cur = sqlite3.connect(path).cursor()
-    for name, avg, n in cur.execute(
-            "select counter_name, avg(value), count(*) from counters_collection "
-            "where kernel_name like ? group by counter_name", (f"%k_poisson<{a.k},%",)):
-        vals[name] = (avg, n)
+# the launch of K passes is k_poisson<K, ...> or, with its tasks in pairs, k_poisson_pairs<K, ...>
+vals, kernel = {}, None
+for form in ("k_poisson_pairs", "k_poisson"):
+    like = f"%{form}<{a.k},%"
+    for path in a.dbs:
+        cur = sqlite3.connect(path).cursor()
+        for name, avg, n in cur.execute(
+                "select counter_name, avg(value), count(*) from counters_collection "
+                "where kernel_name like ? group by counter_name", (like,)):
+            vals[name] = (avg, n)
+    if vals:
+        kernel = form
+        break
+if kernel is None:
+    raise SystemExit(f"no launch of k_poisson<{a.k}, ...> or k_poisson_pairs<{a.k}, ...> in the given databases")
 # the kernel's duration in the pass that counted SQ_BUSY_CYCLES: cycles / duration = the clock it ran at
 launch_us = None
 for path in a.dbs:
     cur = sqlite3.connect(path).cursor()
     has = cur.execute("select count(*) from counters_collection where counter_name = 'SQ_BUSY_CYCLES'").fetchone()[0]
     if has:
-        row = cur.execute("select avg(end - start) from kernels where name like ?", (f"%k_poisson<{a.k},%",)).fetchone()
+        row = cur.execute("select avg(end - start) from kernels where name like ?", (like,)).fetchone()
         if row and row[0]:
             launch_us = row[0] / 1e3
 need = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU")
@@ -55,7 +63,7 @@ for extra in ("SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_
 out = os.path.join(ROOT, "profiles", "poisson_traffic.json")
 with open(out) as f:
     data = json.load(f)
-data[f"k_poisson<{a.k}>"] = entry
+data[f"{kernel}<{a.k}>"] = entry
 with open(out, "w") as f:
     json.dump(data, f, indent=1)
 print(json.dumps(entry))
