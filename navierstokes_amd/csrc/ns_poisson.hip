@@ -351,9 +351,10 @@ int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double 
 
   // Passes per launch and task shape: forced by the options, otherwise the cheapest by the
   // planner's estimate for this grid.
-  // (tasks in pairs: pitched storage, whole-window launches, a caller that may allocate; the planner weighs
-  //  them against plain tasks unless the option says "wherever they fit")
-  const int pairs_likely = aligned && ctx->poisson_pairs && !ctx->no_alloc_call && !ef && (div == DIV_FMA2 || div == DIV_IEEE)
+  // (tasks in pairs: pitched storage, whole-window launches -- of an edges-first call all but the one that is
+  //  cut in three --, a caller that may allocate; the planner weighs them against plain tasks unless the option
+  //  says "wherever they fit")
+  const int pairs_likely = aligned && ctx->poisson_pairs && !ctx->no_alloc_call && (div == DIV_FMA2 || div == DIV_IEEE)
                                ? (ctx->poisson_pairs == 1 ? 1 : 2) : 0;
   const int ep = ctx->poisson_edge_percent;
   const TaskPlan top = choose_plan(nx, ny, ctx->num_simds, aligned, ctx->poisson_k, count < 8 ? count : 8,
@@ -396,6 +397,8 @@ int iters_with_partners(nsk_ctx *ctx, double *Pr, double *dPrdtau, const double 
       A.row2_begin = A.row2_end = 0;
       long simds_left = ctx->num_simds - (pe.tasks + NSK_WAVES - 1) / NSK_WAVES;
       if (simds_left < ctx->num_simds / 2) simds_left = ctx->num_simds / 2;
+      // (plain tasks: workgroups of paired tasks take a quarter of a compute unit's LDS each and left the edge
+      //  tasks no room -- the edge rows were then ready 52 us after the interior was dispatched instead of 13)
       const TaskPlan pi = choose_plan(nx, hi0 - lo1, (int)simds_left, aligned, k, k, ctx->poisson_rows, ep);
       if (int rc = launch_poisson(ctx, ctx->stream, A, aligned, div, pi)) return rc;
       // later work on the context's stream sees the edge rows as well

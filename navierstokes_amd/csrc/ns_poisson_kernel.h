@@ -652,6 +652,15 @@ struct Task {
     // rows that nobody stores
     const int jlast = min(jend + K, r1 - 1 + K);
     if constexpr (DMA) {
+      // A row request writes LDS from the memory side, unordered with the LDS instructions this wavefront has
+      // issued before.  Within a run every step's reads are waited for and the rho/dt * grad V row written in
+      // step j is complete by the wait of step j+1, long before its slot is requested again.  A task that is
+      // run a SECOND time requests its first rows into the slots the first run used last: the scaled row
+      // written in the first run's last step could still be in the LDS queue and land after the freshly
+      // requested row -- which the second run then scaled again.  Seen on a 127 x 1574 grid of subnormal
+      // values in one-pass launches (1574 tasks of two rows, every one run twice): the first output row of a
+      // few tasks per launch wrong, in 22 of 100 calls; none in 400 calls with this wait.
+      lds_wait_all();
 #pragma unroll
       for (int i = 0; i < PFD; i++)
         if (jstart + i <= jend) dma_row(jstart + i, i % NST, i % NSG);
@@ -712,6 +721,9 @@ struct Task {
     }
     return true;
   }
+
+  // The task once more with IEEE division, by a wavefront that has just run its paired form on the same rings.
+  __device__ __forceinline__ void run_again() { run<DIV_IEEE>(); }
 };
 
 #ifdef NSK_POISSON_TRACE
@@ -848,7 +860,7 @@ __global__ void __launch_bounds__(128) NSK_WAVES_ATTR k_poisson_pairs(PoissonArg
       // a plain task with halo rows at both ends, from the launch's inputs -- nothing is needed from the
       // partner, which decides for itself.
       Task<K, true, DIV_IEEE, false, STREAM> again(A, rings, sx, r0, r1);
-      again.run_task();
+      again.run_again();
     }
   } else if (cfirst < 1 || clast > A.nx - 2) {
     Task<K, true, DIV, true, STREAM> t(A, rings, sx, r0, r1);

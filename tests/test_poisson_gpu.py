@@ -350,3 +350,47 @@ def test_edges_first_entry_point(gpu, oracle, pitched):
         gpu.ns_poisson_iters_edges_first(dPr.ptr, dDp.ptr, dDv.ptr, C.byref(cp), 6, 60, 10, 10, 60, C.c_void_p(edge.cuda_stream))
     with pytest.raises(Exception, match="edge_stream is null"):
         gpu.ns_poisson_iters_edges_first(dPr.ptr, dDp.ptr, dDv.ptr, C.byref(cp), 6, 1, 1, 1, 1, None)
+
+
+def test_tasks_run_again_wait_for_all_their_rows(gpu, oracle):
+    """Every task run twice: subnormal pressure values put each task outside the range of the fast division, so
+    it is produced again with IEEE division from the rows its first run has just fetched.  A tall narrow grid
+    in one-pass launches makes ~1500 tasks of two rows that all do so at once.  The second run requests its
+    first rows into the LDS ring slots the first run used last; the first run's last LDS write (the scaled
+    grad V row) could land after the freshly requested row, which was then scaled twice: the first output row
+    of a few tasks per launch was wrong in one call of five.  Repeated, because the failure was a race."""
+    import torch
+    nx, ny = 127, 1574
+    p = ns_params("NavierStokes", nx=nx, ny=ny)
+    rng = np.random.default_rng(903)
+    def field(n, m, scale):
+        f = np.asfortranarray(rng.standard_normal((n, m)) * scale)
+        f[rng.random((n, m)) < 0.3] = 0.0
+        return f
+    Pr0, dP0, dv = field(nx, ny, 1e-310), field(nx - 2, ny - 2, 1e-310), field(nx, ny, 1e-309)
+    edge = torch.cuda.Stream()
+    try:
+        for k, count in ((1, 2), (1, 3), (2, 4)):
+            gpu.set_option("poisson_k", k)
+            Pr, dP = Pr0.copy(order="F"), dP0.copy(order="F")
+            with np.errstate(all="ignore"):
+                oracle_iters(oracle, p, Pr, dP, dv, count, 1)
+            for rep in range(4):
+                gPr, gdP = run_gpu(gpu, p, Pr0, dP0, dv, count, 1, True)
+                assert same_bits(gPr, Pr), (k, count, rep, np.argwhere(gPr != Pr)[:5])
+                assert same_bits(gdP, dP), (k, count, rep, np.argwhere(gdP != dP)[:5])
+                # the last launch cut in three (edge rows on a second stream)
+                ld = _pitch(nx)
+                dPr, dDv = Dev(Pr0, ld, pad_value=np.nan), Dev(dv, ld, pad_value=np.nan)
+                emb = np.full((nx, ny), np.nan, order="F")
+                emb[1:-1, 1:-1] = dP0
+                dDp = Dev(emb, ld, pad_value=np.nan)
+                cp = c_params(p.with_(full_rows=True), ld_pr=ld, dp_embedded=1, ny=ny)
+                gpu.ns_poisson_iters_edges_first(dPr.ptr, dDp.ptr, dDv.ptr, C.byref(cp), count, 0, 369, 732, 0,
+                                                 C.c_void_p(edge.cuda_stream))
+                edge.synchronize()
+                gPr, gdP = dPr.get(), np.asfortranarray(dDp.get()[1:-1, 1:-1])
+                assert same_bits(gPr, Pr), ("edges first", k, count, rep, np.argwhere(gPr != Pr)[:5])
+                assert same_bits(gdP, dP), ("edges first", k, count, rep, np.argwhere(gdP != dP)[:5])
+    finally:
+        gpu.set_option("poisson_k", 0)
