@@ -79,6 +79,8 @@ def sweep(ctx, oracle, cases, seed, max_n, verbose=True):
             K = rows = 0                                  # (a pinned K or task height keeps the launch-per-K-passes kernel)
         scale, zero_frac = [(1.0, 0.0), (1.0, 0.0), (1e-2, 0.0), (1.0, 0.5), (1e-200, 0.0), (1e-300, 0.2), (1e-310, 0.3),
                             (1e200, 0.0), (1e300, 0.0)][int(rng.integers(0, 9))]
+        if os.environ.get("FUZZ_SCALE"):                  # every case at this scale (subnormal: every task run twice)
+            scale, zero_frac = float(os.environ["FUZZ_SCALE"]), 0.3
         p = ns_params("NavierStokes", nx=nx, ny=nyg)
         Pr0 = np.asfortranarray(rng.standard_normal((nx, nyg)) * scale)
         dP0 = np.asfortranarray(rng.standard_normal((nx - 2, nyg - 2)) * scale)
