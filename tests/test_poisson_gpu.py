@@ -276,10 +276,18 @@ def test_planner_picks_passes_per_launch_by_grid(gpu, oracle):
             run_gpu(gpu, p, Pr0, dP0, dv, 40, 0, True)
             assert gpu.get_option("poisson_k") in want, (n, gpu.get_option("poisson_k"))
             assert gpu.get_option("poisson_rows_used") >= 2
+            # tasks in pairs on the benchmark grid (two wavefronts per SIMD either way), plain tasks on the
+            # small one (a strip of one or two chunks has nothing to pair)
+            assert gpu.get_option("poisson_pairs_used") == (1 if n == 16 else 0), n
+        gpu.set_option("poisson_pairs", 0)
+        run_gpu(gpu, p, Pr0, dP0, dv, 12, 0, True)
+        assert gpu.get_option("poisson_pairs_used") == 0
+        gpu.set_option("poisson_pairs", 1)
         run_gpu(gpu, p, Pr0, dP0, dv, 3, 0, True)
         assert gpu.get_option("poisson_k") <= 3
     finally:
         gpu.set_option("poisson_small", 1)
+        gpu.set_option("poisson_pairs", 1)
 
 
 @pytest.mark.parametrize("nx,ny", [(45, 75), (130, 67), (257, 300)])
