@@ -97,7 +97,8 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *                          cover the grid with no more workgroups than compute units)
  *   "poisson_small_spin_limit"  polls before a workgroup gives up on a neighbour (0 = 2^22)
  *   "poisson_small_test_absent" testing: 1 + the workgroup that leaves at once (0 = none)
- *   "poisson_pairs"        launches of "poisson_k" passes on pitched storage: 1 = the tasks of a column strip in
+ *   "poisson_pairs"        launches of "poisson_k" passes on pitched storage (two-operation or IEEE division; not
+ *                          nsk_ns_poisson_iters_static): 1 = the tasks of a column strip in
  *                          pairs that start at a common row and walk away from it, one up and one down the
  *                          array, handing each other that row's values of every pass through LDS, so that
  *                          neither recomputes halo rows at that end -- where the launch planner estimates
