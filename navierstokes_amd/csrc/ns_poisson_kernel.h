@@ -220,6 +220,7 @@ struct Task {
   double *__restrict__ prd;
   ptrdiff_t ld, ldd;  // row strides, negative for a task that walks down the array
   int nyt;            // rows of the window in the task's row numbers (no limit for a task that walks down)
+  int xb_lo;          // PAIR: bc_x! reaches task rows >= xb_lo (a task that walks down) or < A.xbc_rows (xb_lo < 0)
   bool pb, pt;        // row 0 / row nyt-1 of the task's numbering is the window's physical bottom / top
   unsigned xch;       // PAIR: LDS byte address of the exchange area, and which of the two this wavefront is
   int wave;
@@ -246,12 +247,14 @@ struct Task {
       r1 = 2 * mirror + 2 - row0;
       nyt = 1 << 30;
       pb = pt = false;
+      xb_lo = max(2 * mirror + 2 - A.xbc_rows, 0);  // window row 2*mirror + 1 - r < xbc_rows
     } else {
       r0 = row0;
       r1 = row1;
       nyt = A.ny;
       pb = A.phys_bottom != 0;
       pt = A.phys_top != 0;
+      xb_lo = -1;
     }
     jstart = PAIR ? r0 : max(r0 - K, 0);
     jend = min(r1 - 1 + K, nyt - 1);
@@ -394,7 +397,7 @@ struct Task {
   // domain hold don't-care values: nothing reads them and they are never stored.
   __device__ __forceinline__ void edge_fixups(int r, const double cen[2], const double dq[2],
                                               double pnew[2], double dnew[2]) const {
-    if (r < A.xbc_rows) {
+    if (PAIR && xb_lo >= 0 ? r >= xb_lo : r < A.xbc_rows) {
       const double pl = lane_prev(pnew[1]);
       if (c0 == 0) pnew[0] = pnew[1];
       if (c0 + 1 == A.nx - 1) pnew[1] = pnew[0];
@@ -848,19 +851,31 @@ __global__ void __launch_bounds__(128) NSK_WAVES_ATTR k_poisson_pairs(PoissonArg
   constexpr int HK = (K + 1) & ~1;
   constexpr int WOUT = 128 - 2 * HK;
   const int cfirst = sx * WOUT - HK, clast = cfirst + 127;
-  if (kind >= 2) {  // (pairs are made of interior strips only)
+  if (kind >= 2) {
     const unsigned xch = (unsigned)(uintptr_t)(lds_void_t *)(shared + 2 * LDS_VEC);
-    bool ok;
-    {
-      Task<K, true, DIV, false, STREAM, true> t(A, rings, sx, r0, r1, kind == 2 ? r1 - 1 : -1, xch, wave);
-      ok = t.run_task();
-    }
-    if (DIV != DIV_IEEE && !ok) {
-      // A pressure value left the range of the fast division: the task is produced again with IEEE division, as
-      // a plain task with halo rows at both ends, from the launch's inputs -- nothing is needed from the
-      // partner, which decides for itself.
-      Task<K, true, DIV_IEEE, false, STREAM> again(A, rings, sx, r0, r1);
-      again.run_again();
+    // A pressure value left the range of the fast division: the task is produced again with IEEE division, as
+    // a plain task with halo rows at both ends, from the launch's inputs -- nothing is needed from the
+    // partner, which decides for itself.
+    if (cfirst < 1 || clast > A.nx - 2) {  // (a strip with boundary-column work)
+      bool ok;
+      {
+        Task<K, true, DIV, true, STREAM, true> t(A, rings, sx, r0, r1, kind == 2 ? r1 - 1 : -1, xch, wave);
+        ok = t.run_task();
+      }
+      if (DIV != DIV_IEEE && !ok) {
+        Task<K, true, DIV_IEEE, true, STREAM> again(A, rings, sx, r0, r1);
+        again.run_again();
+      }
+    } else {
+      bool ok;
+      {
+        Task<K, true, DIV, false, STREAM, true> t(A, rings, sx, r0, r1, kind == 2 ? r1 - 1 : -1, xch, wave);
+        ok = t.run_task();
+      }
+      if (DIV != DIV_IEEE && !ok) {
+        Task<K, true, DIV_IEEE, false, STREAM> again(A, rings, sx, r0, r1);
+        again.run_again();
+      }
     }
   } else if (cfirst < 1 || clast > A.nx - 2) {
     Task<K, true, DIV, true, STREAM> t(A, rings, sx, r0, r1);
@@ -901,7 +916,7 @@ struct TaskPlan {
   long tasks;
   double est_us_per_pass;
   int nchunks1 = -1, nchunks1_edge = -1;  // chunks that belong to the first of two row ranges (-1: all)
-  bool pairs = false;     // the tasks of the interior strips in pairs (k_poisson_pairs, two tasks per workgroup)
+  bool pairs = false;     // the tasks of every strip in pairs (k_poisson_pairs, two tasks per workgroup)
   long slots = 0;         // wavefront slots the launch takes: the tasks, or two per workgroup
 };
 
@@ -911,6 +926,9 @@ inline bool pairs_fit(int K, int nstrips, int rows, int rows_edge) {
   return 2 * DmaGeometry<1>::LDS_BYTES + 2 * 1024 * (K - 1) + 4096 <= 40960 && nstrips >= 3 && rows >= K + 2 && rows_edge >= 2;
 }
 
+#ifndef NSK_EDGE_PERCENT_PAIRS
+#define NSK_EDGE_PERCENT_PAIRS 62
+#endif
 inline TaskPlan plan_tasks(int K, int nx, int ny, int rows, int edge_percent, bool pairs = false) {
   TaskPlan t;
   const int HK = (K + 1) & ~1, WOUT = 128 - 2 * HK;
@@ -918,9 +936,7 @@ inline TaskPlan plan_tasks(int K, int nx, int ny, int rows, int edge_percent, bo
   t.nstrips = (nx - 1 + WOUT - 1) / WOUT;  // columns 0..nx-2; nx-1 rides with nx-2
   if (rows < 2) rows = 2;
   if (rows > ny) rows = ny;
-  // (with the interior tasks in pairs -- halo rows at one end only -- the tasks that do the boundary-column work,
-  //  which keep theirs at both ends, are cut shorter still)
-  int re = (int)((long)rows * (edge_percent > 0 ? edge_percent : (pairs ? 62 : 75)) / 100);
+  int re = (int)((long)rows * (edge_percent > 0 ? edge_percent : (pairs ? NSK_EDGE_PERCENT_PAIRS : 75)) / 100);
   if (re < 2) re = 2;
   if (re > rows) re = rows;
   t.rows = rows;
@@ -932,14 +948,14 @@ inline TaskPlan plan_tasks(int K, int nx, int ny, int rows, int edge_percent, bo
   t.est_us_per_pass = 0.0;
   t.slots = t.tasks;
   if (pairs && pairs_fit(K, t.nstrips, rows, re)) {
-    // as launch_pairs lists them: per strip one plain chunk, then pairs, a plain one when a chunk is left over;
-    // strips that reach the rim columns plain throughout; plain tasks two per workgroup
-    long npairs = 0, plain = (long)nedge * t.nchunks_edge;
-    const int n = t.nchunks, last_rows = ny - (n - 1) * rows;
-    for (int sx = 1; sx + 1 < t.nstrips; sx++) {
-      const bool rim = sx * WOUT - HK < 1 || sx * WOUT - HK + 127 > nx - 2;
-      if (rim) {  // (cut like the first and the last strip: the boundary-column work rides on its tasks too)
-        plain += t.nchunks_edge;
+    // as launch_pairs lists them: per strip one plain chunk, then pairs, a plain one when a chunk is left over
+    // (chunks of the edge height on strips that reach the rim columns); plain tasks two per workgroup
+    long npairs = 0, plain = 0;
+    for (int sx = 0; sx < t.nstrips; sx++) {
+      const bool edge = sx * WOUT - HK < 1 || sx * WOUT - HK + 127 > nx - 2;
+      const int h = edge ? re : rows, n = edge ? t.nchunks_edge : t.nchunks, last_rows = ny - (n - 1) * h;
+      if (h < K + 2) {  // (too short for the K exchanges)
+        plain += n;
         continue;
       }
       int m = n - 1, p = m / 2, left = m % 2;
@@ -1068,28 +1084,24 @@ int launch_pairs(nsk_ctx *ctx, hipStream_t stream, const PoissonArgs &A, int div
     std::vector<std::pair<int, int>> ch, che;
     cut(plan.rows, ch);
     cut(plan.rows_edge, che);
-    const int n = (int)ch.size();
     constexpr int HK = (K + 1) & ~1, WOUT = 128 - 2 * HK;
-    for (int sx = 1; sx + 1 < plan.nstrips; sx++) {
-      // (a strip whose 128 columns reach the rim columns does the boundary-column work: no pairs there, and
-      //  chunks as short as those of the first and the last strip)
-      if (sx * WOUT - HK < 1 || sx * WOUT - HK + 127 > A.nx - 2) {
-        for (auto &c : che) plain.push_back(PairTask{sx, c.first, c.second, 1});
-        continue;
-      }
-      plain.push_back(PairTask{sx, ch[0].first, ch[0].second, 1});
+    for (int sx = 0; sx < plan.nstrips; sx++) {
+      // (a strip whose 128 columns reach the rim columns does the boundary-column work on top: shorter chunks)
+      const bool edge = sx * WOUT - HK < 1 || sx * WOUT - HK + 127 > A.nx - 2;
+      const std::vector<std::pair<int, int>> &c_ = edge ? che : ch;
+      const int n = (int)c_.size();
+      plain.push_back(PairTask{sx, c_[0].first, c_[0].second, 1});
       for (int c = 1; c < n;) {
-        if (ctx->poisson_pairs != 2 && c + 1 < n && ch[c + 1].second - ch[c + 1].first >= 2) {  // (2: the same launch, no pairs: for timing)
-          groups.push_back(Group{{PairTask{sx, ch[c].first, ch[c].second, 2}, PairTask{sx, ch[c + 1].first, ch[c + 1].second, 3}}});
+        // (2: the same launch, no pairs: for timing; the walker down needs K + 2 rows, its partner 2)
+        if (ctx->poisson_pairs != 2 && c + 1 < n && c_[c].second - c_[c].first >= K + 2 && c_[c + 1].second - c_[c + 1].first >= 2) {
+          groups.push_back(Group{{PairTask{sx, c_[c].first, c_[c].second, 2}, PairTask{sx, c_[c + 1].first, c_[c + 1].second, 3}}});
           c += 2;
         } else {
-          plain.push_back(PairTask{sx, ch[c].first, ch[c].second, 1});
+          plain.push_back(PairTask{sx, c_[c].first, c_[c].second, 1});
           c += 1;
         }
       }
     }
-    for (int side = 0; side < (plan.nstrips >= 2 ? 2 : 1); side++)
-      for (auto &c : che) plain.push_back(PairTask{side == 0 ? 0 : plan.nstrips - 1, c.first, c.second, 1});
     // plain tasks two by two, neighbours in the grid together
     std::sort(plain.begin(), plain.end(), [](const PairTask &a, const PairTask &b) { return a.r0 != b.r0 ? a.r0 < b.r0 : a.sx < b.sx; });
     for (size_t i = 0; i < plain.size(); i += 2)

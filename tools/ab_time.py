@@ -43,4 +43,8 @@ e0.record()
 assert run(6 * launches) == 0
 e1.record()
 torch.cuda.synchronize()
-print(f"{os.path.basename(sys.argv[1])} {nx}x{ny} K={K or 'auto'} rows={ROWS or 'auto'} ld={ld} {os.environ.get('AB_OPTS', '')}: {e0.elapsed_time(e1) * 1e3 / (6 * launches):.2f} us/pass")
+def used(name):
+    v = C.c_int(-1)
+    return v.value if lib.nsk_get_option(h, name, C.byref(v)) else v.value       # (-1: this build has no such option)
+print(f"{os.path.basename(sys.argv[1])} {nx}x{ny} K={K or 'auto'} rows={ROWS or 'auto'} ld={ld} {os.environ.get('AB_OPTS', '')}: {e0.elapsed_time(e1) * 1e3 / (6 * launches):.2f} us/pass"
+      f"   [ran K={used(b'poisson_k')} rows={used(b'poisson_rows_used')} pairs={used(b'poisson_pairs_used')}]")
