@@ -106,7 +106,7 @@ int nsk_use_own_stream(nsk_ctx *ctx);
  *                          3 = in pairs wherever the launch can have them (for tests),
  *                          0 = every task with halo rows at both ends, 2 = the launch shape of 3 without
  *                          pairs (for timing).  NSK_POISSON_PAIRS in the environment sets the default.
- *                          The first and the last strip keep "poisson_edge_percent" (0 = 62 beside pairs).
+ *                          Strips with boundary-column work pair chunks of "poisson_edge_percent" (0 = 62 beside pairs).
  *   "poisson_pairs_used"   (read only) 1 = the last launch of "poisson_k" passes ran its tasks in pairs
  *   "poisson_tall_percent" launches of "poisson_k" passes: interior tasks in pairs of
  *                          poisson_rows * (100 +- this) / 100 rows that start together, so that the last
