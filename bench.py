@@ -298,6 +298,10 @@ def main():
 
     paired = group is None and ctx.get_option("poisson_pairs_used") == 1   # (the launch's tasks in pairs: its own kernel)
     kernel = f"k_poisson_pairs<{kpl}>" if paired else f"k_poisson<{kpl}>"
+    if world > 1 and (ctx.get_option("poisson_pairs") if group is None else 1) == 1:
+        # a slab block ends with the launch that is cut in three (plain tasks, the one the option above reports);
+        # the launches before it run their tasks in pairs where the planner chooses that form
+        kernel = f"k_poisson_pairs<{kpl}>, the last launch of a block k_poisson<{kpl}>"
     cnt = poisson_counters(kernel, nx, slab.ny_win)
     traffic = fabric_frac = valu_frac = valu_sus = clock_sus = None
     if cnt:
