@@ -104,9 +104,10 @@ def test_first_contact_has_a_deadline():
            "--gpus", "2", "--steps", "1", "--warmup", "0", "--passes", "60", "--backend", "gloo", "--one-gpu",
            "--first-contact-s", "6"]
     t0 = time.time()
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT,
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT,
                          env=dict(os.environ, NSK_BENCH_TEST_STALL="1"))
-    assert out.returncode != 0 and time.time() - t0 < 60
+    # (two interpreters start and import torch before the 6 s run; on a busy box that alone has taken most of a minute)
+    assert out.returncode != 0 and time.time() - t0 < 180, (out.returncode, time.time() - t0, out.stderr[-2000:])
     assert "no completion within 6 s -- rank 0 of 2 on cuda:0" in out.stderr, out.stderr[-3000:]
     assert "phase: process group set-up" in out.stderr and "peers [1]" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]        # no result line
