@@ -189,9 +189,11 @@ def main():
                 f"schedule {'abi-slabs' if a.abi_slabs else (a.schedule or 'edges')}")
 
     if world > 1:
+        if os.environ.get("NSK_BENCH_TEST_STALL") == str(rank):
+            # (test of the watchdog: this rank never arrives -- and stays silent, like a hung peer; with a watchdog
+            #  of its own it could leave first and have the launcher end the waiting rank before that one reports)
+            time.sleep(10 * a.first_contact_s)
         with Watchdog(a.first_contact_s, describe):
-            if os.environ.get("NSK_BENCH_TEST_STALL") == str(rank):      # (test of the watchdog: this rank never arrives)
-                time.sleep(10 * a.first_contact_s)
             if a.backend == "nccl":
                 dist.init_process_group("nccl", device_id=dev)
             else:
