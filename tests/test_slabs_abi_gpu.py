@@ -210,7 +210,7 @@ def test_slab_time_step_rejects_a_halo_the_back_trace_would_leave(gpu):
 @pytest.mark.parametrize("edges_first", [1, 0])
 def test_a_transfer_that_does_not_complete_ends_in_an_error(gpu, oracle, edges_first):
     """The host-side waits of a group have a deadline (first_contact_ms until the first exchange has been
-    waited for successfully, deadline_ms afterwards).  An exchange held back on the device for 1.5 s (a
+    waited for successfully, deadline_ms afterwards).  An exchange held back on the device for 3 s (a
     bounded idle kernel where the transfer is queued) against a deadline of 0.3 s: the residual returns
     NSK_ERR_TIMEOUT within the deadline and says which slab waited for what; nothing was aborted on the
     device, so once the idle kernel has ended the same group delivers the right values."""
@@ -225,15 +225,15 @@ def test_a_transfer_that_does_not_complete_ends_in_an_error(gpu, oracle, edges_f
         g.set_option("first_contact_ms", 300)
         g.set_option("deadline_ms", 300)
         load(g, Pr0, dP0, dv)
-        g.set_option("test_stall_ms", 1500)
+        g.set_option("test_stall_ms", 3000)
         t0 = time.perf_counter()
         g.poisson_iters(halo)                       # queues the passes and the (held back) exchange
         with pytest.raises(_lib.NskError, match="no completion within 300 ms on slab .* of 3 .*1 exchanges queued") as e:
             g.residual()
         waited = time.perf_counter() - t0
-        assert e.value.code == _lib.ERR_TIMEOUT and 0.25 < waited < 1.2, waited
+        assert e.value.code == _lib.ERR_TIMEOUT and 0.25 < waited < 2.5, waited   # (well before the idle kernel ends)
         assert "device copies" in str(e.value) and ("edges-first" if edges_first else "plain") in str(e.value)
-        time.sleep(1.5)                             # the idle kernel ends by itself
+        time.sleep(3.0)                             # the idle kernel ends by itself
         g.set_option("deadline_ms", 20000)
         g.set_option("first_contact_ms", 20000)
         m = g.residual()
